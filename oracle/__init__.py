@@ -1,0 +1,173 @@
+"""ctypes bindings for the parity checker.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this
+package.  ``oracle.lib()`` is the C restatement (oracle/phmm_oracle.c); ``oracle.ref()`` is the
+reference's own AVX kernels built from /root/reference into oracle/_ref/ (None when absent or when
+the host CPU lacks AVX-512).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+_REF_TRIED = False
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build():
+    """(Re)build oracle/_build and, where /root/reference exists, oracle/_ref."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def cpu_has_avx512():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return all(x in fl for x in ("avx512f", "avx512dq", "avx512vl", "avx2", "fma"))
+    except OSError:
+        pass
+    return False
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "_build", "libphmm_oracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    pair_args = [u8p, u8p, u8p, u8p, u8p, C.c_uint32, u8p, C.c_uint32]
+    L.phmm_oracle_pair_f32.argtypes = pair_args
+    L.phmm_oracle_pair_f32.restype = C.c_float
+    L.phmm_oracle_pair_f64.argtypes = pair_args
+    L.phmm_oracle_pair_f64.restype = C.c_double
+    L.phmm_oracle_finalize_f32.argtypes = [C.c_float]
+    L.phmm_oracle_finalize_f32.restype = C.c_double
+    L.phmm_oracle_finalize_f64.argtypes = [C.c_double]
+    L.phmm_oracle_finalize_f64.restype = C.c_double
+    for n, t in (("phmm_oracle_ph2pr_f32", C.c_float), ("phmm_oracle_ph2pr_f64", C.c_double),
+                 ("phmm_oracle_mm_table_f32", C.c_float), ("phmm_oracle_mm_table_f64", C.c_double)):
+        getattr(L, n).restype = C.POINTER(t)
+    L.phmm_oracle_mm_prob_f32.argtypes = [C.c_int, C.c_int]
+    L.phmm_oracle_mm_prob_f32.restype = C.c_float
+    L.phmm_oracle_mm_prob_f64.argtypes = [C.c_int, C.c_int]
+    L.phmm_oracle_mm_prob_f64.restype = C.c_double
+    L.phmm_oracle_batch.argtypes = [u8p, u8p, u8p, u8p, u8p, u32p, u32p, u8p, u32p, u32p, u32p, u32p, C.c_uint64,
+                                    f32p, f64p, u8p, C.c_int]
+    L.phmm_oracle_batch.restype = None
+    L.phmm_oracle_modify_quals.argtypes = [u8p, C.c_uint32, C.c_uint8, C.c_int32]
+    L.phmm_oracle_modify_quals.restype = None
+    L.phmm_oracle_find_tandem_repeat_units.argtypes = [u8p, C.c_uint32, C.c_uint32]
+    L.phmm_oracle_find_tandem_repeat_units.restype = C.c_int32
+    L.phmm_oracle_apply_pcr_error_model.argtypes = [u8p, u8p, C.c_uint32, C.c_int]
+    L.phmm_oracle_apply_pcr_error_model.restype = None
+    L.phmm_oracle_normalize.argtypes = [f64p, C.c_uint32, C.c_uint32]
+    L.phmm_oracle_normalize.restype = None
+    L.phmm_oracle_filter.argtypes = [f64p, u32p, C.c_uint32, C.c_uint32, u8p]
+    L.phmm_oracle_filter.restype = C.c_uint32
+    L.phmm_oracle_call_region.argtypes = [u8p, u8p, u32p, u32p, u8p, C.c_uint32, u8p, u32p, u32p, C.c_uint32,
+                                          C.c_int32, C.c_int, f64p, u32p]
+    L.phmm_oracle_call_region.restype = C.c_uint32
+    _LIB = L
+    return L
+
+
+def ref():
+    """The reference's own kernels (oracle/_ref/libphmm_ref.so) or None."""
+    global _REF, _REF_TRIED
+    if _REF_TRIED:
+        return _REF
+    _REF_TRIED = True
+    path = os.path.join(_HERE, "_ref", "libphmm_ref.so")
+    if not os.path.exists(path) or not cpu_has_avx512():
+        return None
+    L = C.CDLL(path)
+    pair_args = [u8p, u8p, u8p, u8p, u8p, C.c_uint32, u8p, C.c_uint32]
+    for n, t in (("ref_pair_avx512_s", C.c_float), ("ref_pair_avx2_s", C.c_float),
+                 ("ref_pair_avx512_d", C.c_double), ("ref_pair_avx2_d", C.c_double)):
+        getattr(L, n).argtypes = pair_args
+        getattr(L, n).restype = t
+    L.ref_init.restype = None
+    L.ref_group_16x1.argtypes = [u8p, u8p, u8p, u8p, u8p, u32p, u32p, u8p, C.c_uint32, f32p]
+    L.ref_group_16x1.restype = None
+    L.ref_tables.argtypes = [f32p, f32p, f64p, f64p]
+    L.ref_tables.restype = None
+    L.ref_regions_16x1.argtypes = [u8p, u8p, u8p, u8p, u8p, u32p, u32p, u8p, u32p, u32p, u32p, u32p, u64p, C.c_uint32,
+                                   f32p, C.c_int]
+    L.ref_regions_16x1.restype = C.c_double
+    L.ref_pairs_avx512_s.argtypes = [u8p, u8p, u8p, u8p, u8p, u32p, u32p, u8p, u32p, u32p, u32p, u32p, C.c_uint64,
+                                     f32p, C.c_int]
+    L.ref_pairs_avx512_s.restype = C.c_double
+    L.ref_init()
+    _REF = L
+    return L
+
+
+# ------------------------------------------------------------------------------------------------
+# numpy-level helpers
+# ------------------------------------------------------------------------------------------------
+MM_TABLE_SIZE = ((254 + 1) * (254 + 2)) >> 1
+
+
+def tables():
+    L = lib()
+    return dict(
+        ph2pr_f32=np.ctypeslib.as_array(L.phmm_oracle_ph2pr_f32(), (128,)).copy(),
+        ph2pr_f64=np.ctypeslib.as_array(L.phmm_oracle_ph2pr_f64(), (128,)).copy(),
+        mm_f32=np.ctypeslib.as_array(L.phmm_oracle_mm_table_f32(), (MM_TABLE_SIZE,)).copy(),
+        mm_f64=np.ctypeslib.as_array(L.phmm_oracle_mm_table_f64(), (MM_TABLE_SIZE,)).copy(),
+    )
+
+
+def ref_tables():
+    R = ref()
+    a = np.zeros(128, np.float32)
+    b = np.zeros(MM_TABLE_SIZE, np.float32)
+    c = np.zeros(128, np.float64)
+    d = np.zeros(MM_TABLE_SIZE, np.float64)
+    R.ref_tables(a, b, c, d)
+    return dict(ph2pr_f32=a, mm_f32=b, ph2pr_f64=c, mm_f64=d)
+
+
+def batch(b, n_threads=1, want_raw=True):
+    """Run the C restatement over a flat batch (rovaca_amd.batch.Batch).  Returns (raw_f32, log10, rescued)."""
+    L = lib()
+    n = int(b.n_pairs)
+    raw = np.zeros(n, np.float32)
+    l10 = np.zeros(n, np.float64)
+    resc = np.zeros(n, np.uint8)
+    L.phmm_oracle_batch(b.read_bases, b.read_qual, b.read_ins, b.read_del, b.read_gcp, b.read_off, b.read_len,
+                        b.hap_bases, b.hap_off, b.hap_len, b.pair_read, b.pair_hap, n, raw, l10, resc, n_threads)
+    return raw, l10, resc.astype(bool)
+
+
+def ref_pairs_avx512_s(b, n_threads=1):
+    """Reference per-pair AVX-512 fp32 kernel over a flat batch.  Returns (raw_f32, seconds)."""
+    R = ref()
+    raw = np.zeros(int(b.n_pairs), np.float32)
+    sec = R.ref_pairs_avx512_s(b.read_bases, b.read_qual, b.read_ins, b.read_del, b.read_gcp, b.read_off, b.read_len,
+                               b.hap_bases, b.hap_off, b.hap_len, b.pair_read, b.pair_hap, int(b.n_pairs), raw,
+                               n_threads)
+    return raw, sec
+
+
+def ref_regions_16x1(b, n_threads=1):
+    """Reference 16x1 AVX-512 kernel over a region-structured batch (needs b.region_*).  (raw_f32, seconds)."""
+    R = ref()
+    raw = np.zeros(int(b.n_pairs), np.float32)
+    sec = R.ref_regions_16x1(b.read_bases, b.read_qual, b.read_ins, b.read_del, b.read_gcp, b.read_off, b.read_len,
+                             b.hap_bases, b.hap_off, b.hap_len, b.region_read, b.region_hap, b.region_pair,
+                             len(b.region_read) - 1, raw, n_threads)
+    return raw, sec

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    path = os.path.join(ROOT, "tests", "golden", "pairhmm_golden.npz")
+    return dict(np.load(path))
+
+
+def golden_batch(g, tag):
+    from rovaca_amd.batch import Batch
+    kw = {k: g[f"{tag}_{k}"] for k in ("read_bases", "read_qual", "read_ins", "read_del", "read_gcp", "read_off",
+                                        "read_len", "hap_bases", "hap_off", "hap_len", "pair_read", "pair_hap")}
+    if f"{tag}_region_read" in g:
+        kw.update(region_read=g[f"{tag}_region_read"], region_hap=g[f"{tag}_region_hap"],
+                  region_pair=g[f"{tag}_region_pair"])
+    return Batch(**kw)
+
+
+GOLDEN_TAGS = ("edge", "c1", "c2", "c3", "noisy")
