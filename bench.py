@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- PairHMM GCUPS on N x MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" is one pass of the hot path (fp32 systolic sweep + rescue collection + fp64 rescue) over one synthetic batch of
+BASELINE config 2 (1 000 000 pairs, reads 150 bp x haplotypes 300 bp) that is already resident in HBM.  With N > 1 every
+rank sweeps its own 1M-pair batch (different seed): the path shards over independent pairs, there is no collective on
+the data path, and the reported value is (cells all ranks processed) / (max over ranks of the wall time) -- weak scaling.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+FLOPS_PER_CELL = 12          # 8 mul + 4 add
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--scale", type=float, default=1.0, help="multiplies the number of regions of the config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+
+    from rovaca_amd import capi, synth
+
+    # each rank owns its own batch (seed offset by rank): the shard of a WGS-scale pair stream this GPU would see
+    cfg = dict(synth.CONFIGS[args.config])
+    cfg["seed"] = cfg["seed"] + 1000 * rank
+    cfg["n_regions"] = max(1, int(round(cfg["n_regions"] * args.scale)))
+    batch = synth.make_batch(**cfg)
+    cells = batch.cells()
+    alg_bytes = batch.algorithmic_bytes()
+
+    eng = capi.Engine(local_rank)
+    rb = eng.upload(batch)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rb.sweep()
+    eng.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    kern_ms = []
+    fp32_ms = []
+    for _ in range(args.steps):
+        ms, ms32 = rb.sweep_timed(1)  # HIP events on the engine's own stream around the launches of this step
+        kern_ms.append(ms)
+        fp32_ms.append(ms32)
+    eng.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    raw, l10, st = rb.download()
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        total_cells = cells * world
+        gcups = total_cells * args.steps / elapsed / 1e9
+        k_ms = float(np.mean(fp32_ms))  # dominant kernel: the fp32 systolic sweep (all launches of one pass)
+        achieved_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
+        valu_tflops = FLOPS_PER_CELL * cells / (k_ms * 1e-3) / 1e12
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(args.config if args.scale == 1.0 else "", None)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "PairHMM GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {batch.n_pairs} pairs/GPU, reads {cfg['read_len']} bp x haps "
+                                   f"{cfg['hap_len']} bp, fp32 + fp64 rescue, regions of {cfg['reads']} reads x "
+                                   f"{cfg['haps']} haps", "pairs_per_gpu": batch.n_pairs, "cells_per_gpu": cells,
+                       "parallelism": f"pair-split x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel": "pairhmm_systolic_kernel<float,K,UG>", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes": alg_bytes},
+            "roofline_valu": {"bound": "fp32-valu", "achieved": round(valu_tflops, 3), "peak": FP32_VALU_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(valu_tflops / FP32_VALU_PEAK_TFLOPS, 5),
+                              "kernel_gcups": round(cells / (k_ms * 1e-3) / 1e9, 2), "flops_per_cell": FLOPS_PER_CELL},
+            "rescued_pairs": int(st.n_rescued), "pass_kernel_ms": round(float(np.mean(kern_ms)), 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"], delta = cpu_baseline(batch, raw, l10, args.cpu_threads)
+            out["max_abs_delta_log10_vs_cpu"] = delta
+    rb.release()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(batch, gpu_raw, gpu_l10, threads):
+    """Time the CPU path beside the GPU number (checker code, never the product): the reference's own AVX-512
+    16-reads x 1-haplotype kernel compiled from /root/reference (oracle/_ref, kind "reference") when the prebuilt
+    library is present and the host has AVX-512, else the scalar C restatement (kind "port") on a bounded sample."""
+    import numpy as np
+
+    import oracle
+    n_cores = os.cpu_count() or 1
+    try:
+        n_cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = threads or n_cores
+    cells = batch.cells()
+    if oracle.ref() is not None:
+        raw, sec = oracle.ref_regions_16x1(batch, n_threads=threads)
+        same = bool(np.array_equal(raw.view(np.uint32), gpu_raw.view(np.uint32)))
+        acc = raw >= np.float32(1e-28)
+        # accepted pairs: identical fp32 sums -> identical log10f on the host; report the measured delta anyway
+        L = oracle.lib()
+        idx = np.nonzero(acc)[0][:: max(1, int(acc.sum()) // 50000)]
+        ref_l10 = np.array([L.phmm_oracle_finalize_f32(float(raw[i])) for i in idx])
+        delta = float(np.abs(ref_l10 - gpu_l10[idx]).max()) if idx.size else 0.0
+        return ({"value": round(cells / sec / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "reference",
+                 "sample": f"all {batch.n_pairs} pairs of the benchmark batch through the reference's "
+                           "compute_full_prob_avx512_float_1xn (16 reads x 1 hap), kernel + lane packing, "
+                           f"{threads} std::threads, {sec:.2f} s", "bit_identical_to_gpu_fp32": same}, delta)
+    # scalar port on a bounded sample (~10-30 s)
+    n = min(batch.n_pairs, max(1000, int(3e9 * threads / 45000 / 10)))
+    sub = batch.subset(np.arange(n))
+    t0 = time.perf_counter()
+    raw, l10, _ = oracle.batch(sub, n_threads=threads)
+    sec = time.perf_counter() - t0
+    delta = float(np.abs(l10 - gpu_l10[:n]).max())
+    return ({"value": round(sub.cells() / sec / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "port",
+             "sample": f"first {n} pairs of the benchmark batch through oracle/phmm_oracle.c (scalar), {sec:.2f} s"}, delta)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,113 @@
+/*
+ * pairhmm_hip.h -- C ABI of the MI355X PairHMM likelihood engine (librovaca_pairhmm_hip.so).
+ *
+ * This is the drop-in boundary for step 3 of Rovaca's HaplotypeCaller.  The reference has no FFI on this path: its seam
+ * is a process-global C++ function pointer plus two per-pair kernel pointers
+ *     rovaca::call_pairhmm                              src/haplotypecaller/pairhmm/pairhmm_engine.h:14-15
+ *     s_compute_full_prob_float_old_pairhmm  (float)    src/haplotypecaller/pairhmm/pairhmm_engine.cpp:8
+ *     s_compute_full_prob_double_old_pairhmm (double)   src/haplotypecaller/pairhmm/pairhmm_engine.cpp:9
+ * bound once in init_pairhmm_ptr (pairhmm_engine.cpp:21-53).  The entry points below are what a GPU candidate for that
+ * seam binds: POD only, caller-owned buffers, int status, no C++ types, no exceptions.  The C++ adapter with the exact
+ * signature of rovaca::call_pairhmm lives in rovaca_amd/host/ (see INTEGRATION.md for the reference-side patch).
+ *
+ * Per-pair semantics are those of the reference's ::TestCase (core/common.h:13-24): read bases and haplotype bases as
+ * ASCII, base quality / insertion gap-open / deletion gap-open / gap-continuation as raw phred bytes (not +33), every
+ * quality masked & 127 (core/avx512_s.cpp:90-93).  Symbols outside ACGTN never match (pairhmm_internal.cpp:27-41).
+ */
+#ifndef ROVACA_AMD_PAIRHMM_HIP_H_
+#define ROVACA_AMD_PAIRHMM_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHMM_ABI_VERSION 1
+
+/* status codes (0 = ok).  Nothing is thrown across this boundary. */
+enum {
+    PHMM_OK = 0,
+    PHMM_E_INVALID = 1,    /* bad argument: null pointer, zero-length read/haplotype, index out of range, read too long */
+    PHMM_E_NO_DEVICE = 2,  /* no usable HIP device: there is NO CPU fallback in this library */
+    PHMM_E_HIP = 3,        /* a HIP runtime call failed; see phmm_last_error() */
+    PHMM_E_NOMEM = 4
+};
+
+/* result acceptance threshold of the fp32 pass and the two scale constants
+ * (rovaca/common.h:9, adapter.h:25-26) */
+#define PHMM_MIN_ACCEPTED_F32 1e-28f
+#define PHMM_LOG10_INITIAL_CONSTANT_F32 36.1236000061f
+#define PHMM_LOG10_INITIAL_CONSTANT_F64 307.050595577260822
+
+typedef struct phmm_context phmm_context; /* device, stream, lookup tables, staging pool */
+typedef struct phmm_resident phmm_resident; /* a batch uploaded to HBM, length-binned, ready to sweep */
+
+/* A batch of N (read, haplotype) pairs over a read table and a haplotype table.
+ * Replaces the per-pair ::TestCase the reference builds at pairhmm_internal.cpp:569-576 / :675-682. */
+typedef struct phmm_batch {
+    uint32_t n_reads;
+    uint32_t n_haps;
+    uint64_t n_pairs;
+    /* read table: five concatenated byte arrays; read k is bytes [read_off[k], read_off[k] + read_len[k]) of each */
+    const uint8_t *read_bases; /* ::TestCase.rs  */
+    const uint8_t *read_qual;  /* ::TestCase.q   */
+    const uint8_t *read_ins;   /* ::TestCase.i   */
+    const uint8_t *read_del;   /* ::TestCase.d   (may alias read_ins, as the reference does: pairhmm_internal.cpp:425) */
+    const uint8_t *read_gcp;   /* ::TestCase.c   */
+    const uint32_t *read_off;
+    const uint32_t *read_len;
+    /* haplotype table */
+    const uint8_t *hap_bases;  /* ::TestCase.hap */
+    const uint32_t *hap_off;
+    const uint32_t *hap_len;
+    /* pair list; both NULL means the full cross product in (read, hap) order: pair p = (p / n_haps, p % n_haps) */
+    const uint32_t *pair_read;
+    const uint32_t *pair_hap;
+} phmm_batch;
+
+typedef struct phmm_stats {
+    uint64_t cells;          /* sum over pairs of read_len * hap_len */
+    uint64_t n_rescued;      /* pairs re-run in fp64 (fp32 sum < 1e-28f) */
+    double kernel_ms;        /* device time of the sweep (fp32 pass + rescue), HIP events on the context's stream */
+    double total_ms;         /* host wall time of the call, uploads and downloads included */
+    uint32_t n_launches;     /* fp32 sweep launches (one per rows-per-lane bin) */
+    uint32_t max_rows_per_lane;
+} phmm_stats;
+
+/* ---- life cycle (replaces the kernel binding half of init_pairhmm_ptr, pairhmm_engine.cpp:43-52) ---- */
+int phmm_abi_version(void);
+int phmm_device_count(void);
+/* device_id >= 0.  stream: a hipStream_t to run on, or NULL to create a private one. */
+int phmm_create(int device_id, void *stream, phmm_context **out);
+void phmm_destroy(phmm_context *ctx);
+const char *phmm_last_error(void); /* thread-local text of the last failure */
+
+/* ---- one-shot: host buffers in, host buffers out.
+ * out_log10[p] = raw >= 1e-28f ? (double)(log10f(raw) - 36.1236000061f) : log10(raw64) - 307.050595577260822
+ * (pairhmm_internal.cpp:577-585); out_raw_f32 (nullable) receives the fp32 sums the first pass produced.
+ * Re-entrant per context; use one context per calling thread (the reference calls this path from up to 128 workers,
+ * haplotypecaller_engine.cpp:119). */
+int phmm_compute(phmm_context *ctx, const phmm_batch *batch, float *out_raw_f32, double *out_log10, phmm_stats *stats);
+
+/* ---- resident batches: upload once, sweep many times (the benchmark's timed region; cross-region batching) ---- */
+int phmm_upload(phmm_context *ctx, const phmm_batch *batch, phmm_resident **out);
+/* enqueue one full pass (fp32 sweep, rescue collection, fp64 rescue) on the context's stream; asynchronous except for
+ * one 4-byte read-back of the rescue count */
+int phmm_sweep(phmm_context *ctx, phmm_resident *rb);
+/* run `iters` passes bracketed by HIP events on the context's stream; *ms_per_pass is the mean device time of a pass,
+ * *fp32_ms_per_pass (nullable) the mean time of the fp32 systolic kernels alone */
+int phmm_sweep_timed(phmm_context *ctx, phmm_resident *rb, int iters, double *ms_per_pass, double *fp32_ms_per_pass);
+/* copy results of the last pass back and finalize on the host (log10f/log10 in glibc, as the reference does) */
+int phmm_download(phmm_context *ctx, phmm_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats);
+int phmm_synchronize(phmm_context *ctx);
+void phmm_release(phmm_context *ctx, phmm_resident *rb);
+
+/* ---- lookup tables the engine built on the host (core/context.h:13-189), for parity checks ---- */
+#define PHMM_MM_TABLE_SIZE 32640 /* ((254 + 1) * (254 + 2)) >> 1 */
+int phmm_get_tables(float *ph2pr_f32 /*[128]*/, float *mm_f32 /*[32640]*/, double *ph2pr_f64 /*[128]*/,
+                    double *mm_f64 /*[32640]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

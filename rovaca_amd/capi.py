@@ -1,0 +1,182 @@
+"""ctypes binding of the C ABI in include/pairhmm_hip.h (rovaca_amd/lib/librovaca_pairhmm_hip.so).
+
+There is no fallback of any kind: if the HIP library is missing or no device is visible this module raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librovaca_pairhmm_hip.so")
+_LIB = None
+
+PHMM_OK = 0
+MM_TABLE_SIZE = 32640
+
+EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy", "phmm_last_error", "phmm_compute",
+           "phmm_upload", "phmm_sweep", "phmm_sweep_timed", "phmm_download", "phmm_synchronize", "phmm_release",
+           "phmm_get_tables")
+
+
+class PhmmBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("n_haps", C.c_uint32), ("n_pairs", C.c_uint64),
+                ("read_bases", C.c_void_p), ("read_qual", C.c_void_p), ("read_ins", C.c_void_p),
+                ("read_del", C.c_void_p), ("read_gcp", C.c_void_p), ("read_off", C.c_void_p), ("read_len", C.c_void_p),
+                ("hap_bases", C.c_void_p), ("hap_off", C.c_void_p), ("hap_len", C.c_void_p),
+                ("pair_read", C.c_void_p), ("pair_hap", C.c_void_p)]
+
+
+class PhmmStats(C.Structure):
+    _fields_ = [("cells", C.c_uint64), ("n_rescued", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("n_launches", C.c_uint32), ("max_rows_per_lane", C.c_uint32)]
+
+
+class PhmmError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True)
+    else:
+        subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True)  # no-op when up to date
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PhmmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(the PairHMM engine has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.phmm_abi_version.restype = C.c_int
+    L.phmm_device_count.restype = C.c_int
+    L.phmm_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.phmm_create.restype = C.c_int
+    L.phmm_destroy.argtypes = [C.c_void_p]
+    L.phmm_destroy.restype = None
+    L.phmm_last_error.restype = C.c_char_p
+    L.phmm_compute.argtypes = [C.c_void_p, C.POINTER(PhmmBatch), C.c_void_p, C.c_void_p, C.POINTER(PhmmStats)]
+    L.phmm_compute.restype = C.c_int
+    L.phmm_upload.argtypes = [C.c_void_p, C.POINTER(PhmmBatch), C.POINTER(C.c_void_p)]
+    L.phmm_upload.restype = C.c_int
+    L.phmm_sweep.argtypes = [C.c_void_p, C.c_void_p]
+    L.phmm_sweep.restype = C.c_int
+    L.phmm_sweep_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.phmm_sweep_timed.restype = C.c_int
+    L.phmm_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PhmmStats)]
+    L.phmm_download.restype = C.c_int
+    L.phmm_synchronize.argtypes = [C.c_void_p]
+    L.phmm_synchronize.restype = C.c_int
+    L.phmm_release.argtypes = [C.c_void_p, C.c_void_p]
+    L.phmm_release.restype = None
+    L.phmm_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.phmm_get_tables.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _check(rc, what):
+    if rc != PHMM_OK:
+        raise PhmmError(f"{what}: status {rc}: {lib().phmm_last_error().decode()}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c_batch(b, cross=False):
+    cb = PhmmBatch()
+    cb.n_reads, cb.n_haps, cb.n_pairs = b.n_reads, b.n_haps, b.n_pairs
+    for k in ("read_bases", "read_qual", "read_ins", "read_del", "read_gcp", "read_off", "read_len", "hap_bases",
+              "hap_off", "hap_len"):
+        setattr(cb, k, _ptr(getattr(b, k)))
+    cb.pair_read = None if cross else _ptr(b.pair_read)
+    cb.pair_hap = None if cross else _ptr(b.pair_hap)
+    return cb
+
+
+def tables():
+    L = lib()
+    a, b = np.zeros(128, np.float32), np.zeros(MM_TABLE_SIZE, np.float32)
+    c, d = np.zeros(128, np.float64), np.zeros(MM_TABLE_SIZE, np.float64)
+    _check(L.phmm_get_tables(_ptr(a), _ptr(b), _ptr(c), _ptr(d)), "phmm_get_tables")
+    return dict(ph2pr_f32=a, mm_f32=b, ph2pr_f64=c, mm_f64=d)
+
+
+class Resident:
+    """A batch living in HBM (phmm_upload)."""
+
+    def __init__(self, engine, handle, n_pairs):
+        self.engine, self.handle, self.n_pairs = engine, handle, n_pairs
+
+    def sweep(self):
+        _check(lib().phmm_sweep(self.engine.handle, self.handle), "phmm_sweep")
+
+    def sweep_timed(self, iters=1):
+        ms, ms32 = C.c_double(), C.c_double()
+        _check(lib().phmm_sweep_timed(self.engine.handle, self.handle, iters, C.byref(ms), C.byref(ms32)), "phmm_sweep_timed")
+        return ms.value, ms32.value
+
+    def download(self):
+        raw = np.zeros(self.n_pairs, np.float32)
+        l10 = np.zeros(self.n_pairs, np.float64)
+        st = PhmmStats()
+        _check(lib().phmm_download(self.engine.handle, self.handle, _ptr(raw), _ptr(l10), C.byref(st)), "phmm_download")
+        return raw, l10, st
+
+    def release(self):
+        if self.handle:
+            lib().phmm_release(self.engine.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One context (device + stream + tables).  ``stream``: integer hipStream_t or None for a private stream."""
+
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        h = C.c_void_p()
+        _check(L.phmm_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)), "phmm_create")
+        self.handle = h
+
+    def compute(self, batch, cross=False):
+        """Host buffers in, (raw_f32, log10, stats) out."""
+        cb = _c_batch(batch, cross)
+        n = batch.n_reads * batch.n_haps if cross else batch.n_pairs
+        raw = np.zeros(n, np.float32)
+        l10 = np.zeros(n, np.float64)
+        st = PhmmStats()
+        _check(lib().phmm_compute(self.handle, C.byref(cb), _ptr(raw), _ptr(l10), C.byref(st)), "phmm_compute")
+        return raw, l10, st
+
+    def upload(self, batch, cross=False):
+        cb = _c_batch(batch, cross)
+        h = C.c_void_p()
+        _check(lib().phmm_upload(self.handle, C.byref(cb), C.byref(h)), "phmm_upload")
+        return Resident(self, h, batch.n_reads * batch.n_haps if cross else batch.n_pairs)
+
+    def synchronize(self):
+        _check(lib().phmm_synchronize(self.handle), "phmm_synchronize")
+
+    def close(self):
+        if self.handle:
+            lib().phmm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

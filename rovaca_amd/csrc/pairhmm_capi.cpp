@@ -1,0 +1,505 @@
+// pairhmm_capi.cpp -- the extern "C" boundary of include/pairhmm_hip.h: contexts, resident batches, length binning,
+// launches, rescue, host finalisation.  Host C++ over the HIP runtime; no CPU compute path (there is no fallback:
+// without a device phmm_create fails with PHMM_E_NO_DEVICE).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pairhmm_hip.h"
+#include "pairhmm_device.h"
+#include "pairhmm_tables.h"
+
+namespace
+{
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e__ = (expr);                                                                               \
+        if (e__ != hipSuccess) return fail(PHMM_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));        \
+    } while (0)
+
+template <typename T>
+struct DevBuf
+{
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    void reset()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        reset();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    }
+    hipError_t upload(const T *src, size_t count, hipStream_t s)
+    {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+};
+
+}  // namespace
+
+struct phmm_context
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf<float> ph2pr_f32, mm_f32;
+    DevBuf<double> ph2pr_f64, mm_f64;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct Bin
+{
+    int rows_per_lane;
+    uint32_t first, count;  // range of `order`
+    uint32_t lds_words_per_group;
+};
+
+struct phmm_resident
+{
+    uint64_t n_pairs = 0, cells = 0;
+    uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0;
+    bool uniform_gcp = false;
+    DevBuf<uint8_t> read_bases, read_qual, read_ins, read_del, read_gcp, hap_bases;
+    DevBuf<uint32_t> read_off, read_len, hap_off, hap_len, pair_read, pair_hap, order;
+    DevBuf<uint32_t> planes, plane_off, word_owner;
+    DevBuf<float> raw32;
+    DevBuf<double> raw64;
+    DevBuf<uint32_t> rescue_list, rescue_count;
+    DevBuf<double> scratch;
+    uint32_t scratch_pairs = 0;
+    std::vector<Bin> bins;
+    uint32_t last_rescued = 0;
+    double last_kernel_ms = 0.0;
+};
+
+extern "C" {
+
+int phmm_abi_version(void) { return PHMM_ABI_VERSION; }
+
+const char *phmm_last_error(void) { return g_err; }
+
+int phmm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int phmm_get_tables(float *ph2pr_f32, float *mm_f32, double *ph2pr_f64, double *mm_f64)
+{
+    const phmm::HostTables &t = phmm::host_tables();
+    if (ph2pr_f32) memcpy(ph2pr_f32, t.ph2pr_f32.data(), 128 * sizeof(float));
+    if (mm_f32) memcpy(mm_f32, t.mm_f32.data(), phmm::kMmTableSize * sizeof(float));
+    if (ph2pr_f64) memcpy(ph2pr_f64, t.ph2pr_f64.data(), 128 * sizeof(double));
+    if (mm_f64) memcpy(mm_f64, t.mm_f64.data(), phmm::kMmTableSize * sizeof(double));
+    return PHMM_OK;
+}
+
+int phmm_create(int device_id, void *stream, phmm_context **out)
+{
+    if (!out || device_id < 0) return fail(PHMM_E_INVALID, "phmm_create: bad arguments");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(PHMM_E_NO_DEVICE, "phmm_create: no HIP device visible (this engine has no CPU fallback)");
+    if (device_id >= n) return fail(PHMM_E_NO_DEVICE, "phmm_create: device %d of %d does not exist", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    phmm_context *c = new (std::nothrow) phmm_context();
+    if (!c) return fail(PHMM_E_NOMEM, "phmm_create: out of host memory");
+    c->device = device_id;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(PHMM_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    const phmm::HostTables &t = phmm::host_tables();
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = c->ph2pr_f32.upload(t.ph2pr_f32.data(), 128, c->stream);
+    if (e == hipSuccess) e = c->mm_f32.upload(t.mm_f32.data(), phmm::kMmTableSize, c->stream);
+    if (e == hipSuccess) e = c->ph2pr_f64.upload(t.ph2pr_f64.data(), 128, c->stream);
+    if (e == hipSuccess) e = c->mm_f64.upload(t.mm_f64.data(), phmm::kMmTableSize, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        phmm_destroy(c);
+        return fail(PHMM_E_HIP, "phmm_create: table upload failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return PHMM_OK;
+}
+
+void phmm_destroy(phmm_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int phmm_synchronize(phmm_context *c)
+{
+    if (!c) return fail(PHMM_E_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PHMM_OK;
+}
+
+void phmm_release(phmm_context *c, phmm_resident *rb)
+{
+    if (!rb) return;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    delete rb;
+}
+
+int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
+{
+    if (!c || !b || !out) return fail(PHMM_E_INVALID, "phmm_upload: null argument");
+    *out = nullptr;
+    if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
+        return fail(PHMM_E_INVALID, "phmm_upload: pair_read and pair_hap must both be given or both be NULL");
+    const bool cross = b->pair_read == nullptr;
+    const uint64_t n_pairs = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
+    if (n_pairs > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_upload: more than 2^32 pairs in one batch");
+    if (n_pairs && (!b->read_bases || !b->read_qual || !b->read_ins || !b->read_del || !b->read_gcp || !b->read_off ||
+                    !b->read_len || !b->hap_bases || !b->hap_off || !b->hap_len))
+        return fail(PHMM_E_INVALID, "phmm_upload: null table pointer");
+    HIP_TRY(hipSetDevice(c->device));
+
+    // ---- validate the tables, find extents ----
+    uint64_t read_bytes = 0, hap_bytes = 0;
+    uint32_t max_hap = 0, max_read = 0;
+    for (uint32_t r = 0; r < b->n_reads; ++r) {
+        if (b->read_len[r] == 0) return fail(PHMM_E_INVALID, "phmm_upload: read %u has length 0", r);
+        read_bytes = std::max<uint64_t>(read_bytes, (uint64_t)b->read_off[r] + b->read_len[r]);
+        max_read = std::max(max_read, b->read_len[r]);
+    }
+    for (uint32_t h = 0; h < b->n_haps; ++h) {
+        if (b->hap_len[h] == 0) return fail(PHMM_E_INVALID, "phmm_upload: haplotype %u has length 0", h);
+        hap_bytes = std::max<uint64_t>(hap_bytes, (uint64_t)b->hap_off[h] + b->hap_len[h]);
+        max_hap = std::max(max_hap, b->hap_len[h]);
+    }
+    if (max_read > (uint32_t)(phmm::kLanesPerPair * phmm::kMaxRowsPerLane))
+        return fail(PHMM_E_INVALID, "phmm_upload: read of %u bases exceeds the %d-row single-pass kernel", max_read,
+                    phmm::kLanesPerPair * phmm::kMaxRowsPerLane);
+
+    phmm_resident *rb = new (std::nothrow) phmm_resident();
+    if (!rb) return fail(PHMM_E_NOMEM, "phmm_upload: out of host memory");
+    struct Guard
+    {
+        phmm_resident *p;
+        ~Guard() { delete p; }
+    } guard{rb};
+    rb->n_pairs = n_pairs;
+    rb->n_reads = b->n_reads;
+    rb->n_haps = b->n_haps;
+    rb->max_hap_len = max_hap;
+
+    // ---- pair list (materialise the cross product), length binning ----
+    std::vector<uint32_t> pr(n_pairs), ph(n_pairs);
+    if (cross) {
+        for (uint64_t p = 0; p < n_pairs; ++p) {
+            pr[p] = (uint32_t)(p / b->n_haps);
+            ph[p] = (uint32_t)(p % b->n_haps);
+        }
+    }
+    else {
+        for (uint64_t p = 0; p < n_pairs; ++p) {
+            if (b->pair_read[p] >= b->n_reads || b->pair_hap[p] >= b->n_haps)
+                return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)p);
+            pr[p] = b->pair_read[p];
+            ph[p] = b->pair_hap[p];
+        }
+    }
+    // key = (rows per lane, haplotype length): one launch per rows-per-lane value, waves of near-equal sweep length
+    std::vector<uint64_t> keys(n_pairs);
+    uint64_t cells = 0;
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        const uint32_t R = b->read_len[pr[p]], H = b->hap_len[ph[p]];
+        const uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
+        cells += (uint64_t)R * H;
+        keys[p] = ((uint64_t)K << 56) | ((uint64_t)H << 32) | p;
+    }
+    std::sort(keys.begin(), keys.end());
+    std::vector<uint32_t> order(n_pairs);
+    for (uint64_t i = 0; i < n_pairs; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+    for (uint64_t i = 0; i < n_pairs;) {
+        const int K = (int)(keys[i] >> 56);
+        uint64_t j = i;
+        uint32_t hmax = 0;
+        while (j < n_pairs && (int)(keys[j] >> 56) == K) {
+            hmax = std::max(hmax, (uint32_t)((keys[j] >> 32) & 0xFFFFFFu));
+            ++j;
+        }
+        const uint32_t lds_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
+        if ((uint64_t)lds_words * (phmm::kBlockThreads / phmm::kLanesPerPair) * sizeof(uint32_t) > 64u * 1024u)
+            return fail(PHMM_E_INVALID, "phmm_upload: haplotype of %u bases exceeds the LDS plane budget of this kernel", hmax);
+        rb->bins.push_back(Bin{K, (uint32_t)i, (uint32_t)(j - i), lds_words});
+        i = j;
+    }
+    rb->cells = cells;
+
+    // uniform gap-continuation penalty (the Rovaca case) selects the kernel variant with shared p_gapm / p_xx
+    bool ug = read_bytes > 0;
+    {
+        const uint8_t c0 = read_bytes ? (b->read_gcp[b->read_off[0]] & 127) : 0;
+        for (uint32_t r = 0; r < b->n_reads && ug; ++r) {
+            const uint8_t *g = b->read_gcp + b->read_off[r];
+            for (uint32_t i = 0; i < b->read_len[r]; ++i)
+                if ((g[i] & 127) != c0) {
+                    ug = false;
+                    break;
+                }
+        }
+    }
+    rb->uniform_gcp = ug;
+
+    // ---- haplotype plane layout ----
+    std::vector<uint32_t> plane_off(b->n_haps), owner;
+    uint64_t slots = 0;
+    for (uint32_t h = 0; h < b->n_haps; ++h) {
+        plane_off[h] = (uint32_t)(slots * phmm::kPlanes);
+        slots += phmm::planes_words(b->hap_len[h]);
+    }
+    if (slots * phmm::kPlanes > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_upload: haplotype table too large");
+    owner.resize(slots);
+    {
+        uint64_t s = 0;
+        for (uint32_t h = 0; h < b->n_haps; ++h)
+            for (uint32_t w = 0; w < phmm::planes_words(b->hap_len[h]); ++w) owner[s++] = h;
+    }
+
+    // ---- upload ----
+    hipStream_t st = c->stream;
+    HIP_TRY(rb->read_bases.upload(b->read_bases, read_bytes, st));
+    HIP_TRY(rb->read_qual.upload(b->read_qual, read_bytes, st));
+    HIP_TRY(rb->read_ins.upload(b->read_ins, read_bytes, st));
+    HIP_TRY(rb->read_del.upload(b->read_del, read_bytes, st));
+    HIP_TRY(rb->read_gcp.upload(b->read_gcp, read_bytes, st));
+    HIP_TRY(rb->read_off.upload(b->read_off, b->n_reads, st));
+    HIP_TRY(rb->read_len.upload(b->read_len, b->n_reads, st));
+    HIP_TRY(rb->hap_bases.upload(b->hap_bases, hap_bytes, st));
+    HIP_TRY(rb->hap_off.upload(b->hap_off, b->n_haps, st));
+    HIP_TRY(rb->hap_len.upload(b->hap_len, b->n_haps, st));
+    HIP_TRY(rb->pair_read.upload(pr.data(), n_pairs, st));
+    HIP_TRY(rb->pair_hap.upload(ph.data(), n_pairs, st));
+    HIP_TRY(rb->order.upload(order.data(), n_pairs, st));
+    HIP_TRY(rb->plane_off.upload(plane_off.data(), b->n_haps, st));
+    HIP_TRY(rb->word_owner.upload(owner.data(), slots, st));
+    HIP_TRY(rb->planes.alloc(slots * phmm::kPlanes));
+    HIP_TRY(rb->raw32.alloc(n_pairs));
+    HIP_TRY(rb->raw64.alloc(n_pairs));
+    HIP_TRY(rb->rescue_list.alloc(n_pairs));
+    HIP_TRY(rb->rescue_count.alloc(1));
+    if (n_pairs) {
+        HIP_TRY(hipMemsetAsync(rb->raw64.p, 0, n_pairs * sizeof(double), st));
+        HIP_TRY(phmm::launch_hap_planes(rb->hap_bases.p, rb->hap_off.p, rb->hap_len.p, rb->plane_off.p, rb->word_owner.p,
+                                        (uint32_t)slots, rb->planes.p, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));  // the host vectors above die at return
+    guard.p = nullptr;
+    *out = rb;
+    return PHMM_OK;
+}
+
+static int sweep_fp32(phmm_context *c, phmm_resident *rb)
+{
+    for (const Bin &bin : rb->bins) {
+        phmm::KernelArgs a{};
+        a.read_bases = rb->read_bases.p;
+        a.read_qual = rb->read_qual.p;
+        a.read_ins = rb->read_ins.p;
+        a.read_del = rb->read_del.p;
+        a.read_gcp = rb->read_gcp.p;
+        a.read_off = rb->read_off.p;
+        a.read_len = rb->read_len.p;
+        a.hap_len = rb->hap_len.p;
+        a.planes = rb->planes.p;
+        a.plane_off = rb->plane_off.p;
+        a.pair_read = rb->pair_read.p;
+        a.pair_hap = rb->pair_hap.p;
+        a.order = rb->order.p + bin.first;
+        a.n_pairs = bin.count;
+        a.lds_words_per_group = bin.lds_words_per_group;
+        a.ph2pr = c->ph2pr_f32.p;
+        a.mm_table = c->mm_f32.p;
+        a.out_raw = rb->raw32.p;
+        HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, c->stream));
+    }
+    return PHMM_OK;
+}
+
+static int sweep_rescue(phmm_context *c, phmm_resident *rb)
+{
+    if (rb->n_pairs == 0) return PHMM_OK;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, sizeof(uint32_t), st));
+    HIP_TRY(phmm::launch_collect_rescue(rb->raw32.p, (uint32_t)rb->n_pairs, rb->rescue_list.p, rb->rescue_count.p,
+                                        (uint32_t)rb->n_pairs, st));
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, rb->rescue_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rb->last_rescued = n;
+    if (n == 0) return PHMM_OK;
+    const uint32_t stride = rb->max_hap_len + 1;
+    if (rb->scratch_pairs < n) {
+        HIP_TRY(rb->scratch.alloc((size_t)n * 3 * stride));
+        rb->scratch_pairs = n;
+    }
+    phmm::RescueArgs a{};
+    a.read_bases = rb->read_bases.p;
+    a.read_qual = rb->read_qual.p;
+    a.read_ins = rb->read_ins.p;
+    a.read_del = rb->read_del.p;
+    a.read_gcp = rb->read_gcp.p;
+    a.read_off = rb->read_off.p;
+    a.read_len = rb->read_len.p;
+    a.hap_bases = rb->hap_bases.p;
+    a.hap_off = rb->hap_off.p;
+    a.hap_len = rb->hap_len.p;
+    a.pair_read = rb->pair_read.p;
+    a.pair_hap = rb->pair_hap.p;
+    a.rescue_list = rb->rescue_list.p;
+    a.n_rescue = rb->rescue_count.p;
+    a.ph2pr = c->ph2pr_f64.p;
+    a.mm_table = c->mm_f64.p;
+    a.scratch = rb->scratch.p;
+    a.scratch_stride = stride;
+    a.out_raw64 = rb->raw64.p;
+    HIP_TRY(phmm::launch_rescue_f64(a, n, st));
+    return PHMM_OK;
+}
+
+int phmm_sweep(phmm_context *c, phmm_resident *rb)
+{
+    if (!c || !rb) return fail(PHMM_E_INVALID, "phmm_sweep: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sweep_fp32(c, rb);
+    if (rc != PHMM_OK) return rc;
+    return sweep_rescue(c, rb);
+}
+
+int phmm_sweep_timed(phmm_context *c, phmm_resident *rb, int iters, double *ms_per_pass, double *fp32_ms_per_pass)
+{
+    if (!c || !rb || iters < 1 || !ms_per_pass) return fail(PHMM_E_INVALID, "phmm_sweep_timed: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    double total = 0.0, fp32 = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        float ms_a = 0.f, ms_b = 0.f;
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        int rc = sweep_fp32(c, rb);
+        if (rc != PHMM_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms_a, c->ev0, c->ev1));
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        rc = sweep_rescue(c, rb);
+        if (rc != PHMM_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms_b, c->ev0, c->ev1));
+        fp32 += ms_a;
+        total += (double)ms_a + ms_b;
+    }
+    *ms_per_pass = total / iters;
+    if (fp32_ms_per_pass) *fp32_ms_per_pass = fp32 / iters;
+    rb->last_kernel_ms = total / iters;
+    return PHMM_OK;
+}
+
+int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats)
+{
+    if (!c || !rb) return fail(PHMM_E_INVALID, "phmm_download: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t n = rb->n_pairs;
+    std::vector<float> raw;
+    float *rp = out_raw_f32;
+    if (!rp && out_log10) {
+        raw.resize(n);
+        rp = raw.data();
+    }
+    if (rp && n) HIP_TRY(hipMemcpyAsync(rp, rb->raw32.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> r64;
+    if (out_log10 && rb->last_rescued && n) {
+        r64.resize(n);
+        HIP_TRY(hipMemcpyAsync(r64.data(), rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (out_log10) {
+        // pairhmm_internal.cpp:577-585 -- libm on the host, as the reference does, so the last ulp agrees
+        for (uint64_t p = 0; p < n; ++p) {
+            const float x = rp[p];
+            if (x < PHMM_MIN_ACCEPTED_F32)
+                out_log10[p] = log10(r64.empty() ? 0.0 : r64[p]) - PHMM_LOG10_INITIAL_CONSTANT_F64;
+            else
+                out_log10[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
+        }
+    }
+    if (stats) {
+        stats->cells = rb->cells;
+        stats->n_rescued = rb->last_rescued;
+        stats->kernel_ms = rb->last_kernel_ms;
+        stats->n_launches = (uint32_t)rb->bins.size();
+        stats->max_rows_per_lane = rb->bins.empty() ? 0 : (uint32_t)rb->bins.back().rows_per_lane;
+    }
+    return PHMM_OK;
+}
+
+int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    phmm_resident *rb = nullptr;
+    int rc = phmm_upload(c, b, &rb);
+    if (rc != PHMM_OK) return rc;
+    double ms = 0.0;
+    rc = phmm_sweep_timed(c, rb, 1, &ms, nullptr);
+    if (rc == PHMM_OK) rc = phmm_download(c, rb, out_raw_f32, out_log10, stats);
+    phmm_release(c, rb);
+    if (rc == PHMM_OK && stats)
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// pairhmm_device.h -- shared between the device code (pairhmm_kernels.hip) and the C-ABI host code (pairhmm_capi.cpp).
+#ifndef ROVACA_AMD_PAIRHMM_DEVICE_H_
+#define ROVACA_AMD_PAIRHMM_DEVICE_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phmm
+{
+
+constexpr int kLanesPerPair = 16;     // one DPP row per (read, haplotype) pair; four pairs per wave64
+constexpr int kBlockThreads = 256;    // 4 waves = 16 pairs per workgroup
+constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take the single-pass kernel
+constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other
+
+// 32-bit words per haplotype match plane (column j, 1-based, is bit 31-((j-1)&31) of word (j-1)>>5); one spare
+// word so that a window read [w, w+1] at the last sweep step (column H + 15) stays inside the plane
+__host__ __device__ inline uint32_t planes_words(uint32_t hap_len) { return ((hap_len + 14u) >> 5) + 2u; }
+
+struct KernelArgs
+{
+    // read table (raw phred bytes, ::TestCase semantics, core/common.h:13-24)
+    const uint8_t *read_bases, *read_qual, *read_ins, *read_del, *read_gcp;
+    const uint32_t *read_off, *read_len;
+    // haplotype table: lengths and the precomputed match planes
+    const uint32_t *hap_len;
+    const uint32_t *planes;
+    const uint32_t *plane_off;
+    // pair list and the length-binned processing order of this launch
+    const uint32_t *pair_read, *pair_hap;
+    const uint32_t *order;
+    uint32_t n_pairs;
+    uint32_t lds_words_per_group;
+    // lookup tables (core/context.h) in the arithmetic type of the launch
+    const void *ph2pr;
+    const void *mm_table;
+    void *out_raw;  // [n_pairs of the whole batch], indexed by pair id
+};
+
+struct RescueArgs
+{
+    const uint8_t *read_bases, *read_qual, *read_ins, *read_del, *read_gcp;
+    const uint32_t *read_off, *read_len;
+    const uint8_t *hap_bases;
+    const uint32_t *hap_off, *hap_len;
+    const uint32_t *pair_read, *pair_hap;
+    const uint32_t *rescue_list;
+    const uint32_t *n_rescue;
+    const double *ph2pr;
+    const double *mm_table;
+    double *scratch;        // 3 * scratch_stride doubles per rescued pair
+    uint32_t scratch_stride;
+    double *out_raw64;      // indexed by pair id
+};
+
+hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const KernelArgs &a, hipStream_t s);
+hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
+                             const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,
+                             hipStream_t s);
+hipError_t launch_collect_rescue(const float *raw, uint32_t n_pairs, uint32_t *list, uint32_t *count, uint32_t capacity,
+                                 hipStream_t s);
+hipError_t launch_rescue_f64(const RescueArgs &a, uint32_t max_rescue, hipStream_t s);
+
+}  // namespace phmm
+#endif

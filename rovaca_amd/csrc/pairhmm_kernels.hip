@@ -1,0 +1,407 @@
+// pairhmm_kernels.hip -- gfx950 (MI355X) device code for the PairHMM forward recurrence.
+//
+// What is computed (per pair, identical to the reference's AVX-512 kernels, bit for bit in fp32):
+//   rovaca/avx_512_float.cc:29-181 (compute_full_prob_avx512_float_1xn) == core/avx512_s.cpp:259-397
+//   (compute_fp_avx512_s), with GCC's FMA contraction of those translation units made explicit:
+//     t = Md*p_mm; t = fma(Xd,p_gapm,t); t = fma(Yd,p_gapm,t); M = t*prior
+//     X = fma(Xu,p_xx, Mu*p_mx);  Y = fma(Yl,p_yy, Ml*p_my)
+//   result = (sum_j M[R][j]) + (sum_j X[R][j]), both sums left to right.
+//
+// How it is mapped to CDNA4:
+//   * a wave64 is four independent 16-lane systolic arrays (one DPP row each); one (read, haplotype) pair
+//     per 16 lanes, so one wave sweeps four pairs at a time;
+//   * lane l of a group owns K consecutive read rows (K = ceil(R/16), a template parameter), kept entirely
+//     in VGPRs: per-row transition/prior constants and the M/X/Y values of the current anti-diagonal;
+//   * time step t: lane l computes column t-l of its K rows; the only cross-lane traffic is the last row of
+//     lane l-1 (three `v_mov_b32_dpp row_shr:1` per step, i.e. 3/K per cell);
+//   * the read-vs-haplotype comparison is bit-parallel: a prologue kernel turns every haplotype into six
+//     bit planes ("does column j match read symbol class c"), staged in LDS per pair; each row keeps a
+//     32-column window of its plane in one VGPR and consumes it with `v_add_co_u32` (shift + carry-out) and
+//     one `v_cndmask_b32` per cell;
+//   * rows are right-aligned in the 16*K slots, so the last read row is always slot K-1 of lane 15 and the
+//     final sum is accumulated there in the reference's order.  Padding rows above the read reproduce the
+//     boundary row (M = X = 0, Y = 2^120/H) exactly.
+//
+// No MFMA: this is a first-order recurrence, not a contraction.  No CUDA-isms: wave64, DPP, LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pairhmm_device.h"
+
+namespace phmm
+{
+
+// ----------------------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_row_shr1(float old, float src)
+{
+    // lane i of each 16-lane row receives lane i-1; lane 0 of the row keeps `old`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x111, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ double dpp_row_shr1(double old, double src)
+{
+    union { double d; int i[2]; } o, s, r;
+    o.d = old;
+    s.d = src;
+    r.i[0] = __builtin_amdgcn_update_dpp(o.i[0], s.i[0], 0x111, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], s.i[1], 0x111, 0xF, 0xF, false);
+    return r.d;
+}
+
+// read symbol -> plane class: A C G T N other  (one-hot semantics of pairhmm_internal.cpp:27-41)
+__device__ __forceinline__ uint32_t read_class(uint8_t b)
+{
+    return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : b == 'N' ? 4u : 5u;
+}
+
+template <typename T> struct Num;
+template <> struct Num<float>
+{
+    __device__ static float init_const() { return __builtin_ldexpf(1.0f, 120); }  // core/context.h:148
+    __device__ static float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    __device__ static float div3(float x) { return __fdiv_rn(x, 3.0f); }
+};
+template <> struct Num<double>
+{
+    __device__ static double init_const() { return __builtin_ldexp(1.0, 1020); }  // core/context.h:106
+    __device__ static double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    __device__ static double div3(double x) { return __ddiv_rn(x, 3.0); }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// haplotype bit planes.  One thread per (haplotype, 32-column word).  Column j (1-based) is bit
+// 31 - ((j-1) & 31) of word (j-1) >> 5: MSB first, so that `v_add_co_u32 m, vcc, m, m` pops the next column.
+//   plane 0..3: read base A/C/G/T matches this column (hap base equal, or hap base N)
+//   plane 4   : read base N matches this column (hap base is any of ACGTN)
+//   plane 5   : read symbol outside ACGTN: never matches (all zero)
+// Words past the haplotype end are zero.
+// ----------------------------------------------------------------------------------------------------
+__global__ void hap_planes_kernel(const uint8_t *__restrict__ hap_bases, const uint32_t *__restrict__ hap_off,
+                                  const uint32_t *__restrict__ hap_len, const uint32_t *__restrict__ plane_off,
+                                  const uint32_t *__restrict__ word_owner, uint32_t n_words, uint32_t *__restrict__ planes)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_words) return;
+    // word_owner[g] = haplotype that owns global word slot g; the slot index inside that haplotype follows
+    uint32_t h = word_owner[g];
+    uint32_t H = hap_len[h];
+    uint32_t W = planes_words(H);
+    uint32_t w = g - (plane_off[h] / kPlanes);  // plane_off is in words and counts kPlanes * W per haplotype
+    const uint8_t *hb = hap_bases + hap_off[h];
+    uint32_t bits[kPlanes] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t b = 0; b < 32; ++b) {
+        uint32_t j0 = w * 32 + b;
+        if (j0 < H) {
+            uint8_t c = hb[j0];
+            uint32_t bit = 0x80000000u >> b;
+            bool isN = c == 'N';
+            if (c == 'A' || isN) bits[0] |= bit;
+            if (c == 'C' || isN) bits[1] |= bit;
+            if (c == 'G' || isN) bits[2] |= bit;
+            if (c == 'T' || isN) bits[3] |= bit;
+            if (c == 'A' || c == 'C' || c == 'G' || c == 'T' || isN) bits[4] |= bit;
+        }
+    }
+    uint32_t *dst = planes + plane_off[h];
+    for (int c = 0; c < kPlanes; ++c) dst[c * W + w] = bits[c];
+}
+
+// ----------------------------------------------------------------------------------------------------
+// the systolic kernel
+// ----------------------------------------------------------------------------------------------------
+template <typename T, int K, bool UG>
+struct Rows
+{
+    // per-row constants.  UG ("uniform gap continuation", the Rovaca case: read_record.cpp:205-210 fixes gcp = 10)
+    // shares p_gapm and p_xx across rows; p_yy stays per row because a padding row needs p_yy = 1.
+    T p_mm[K], p_mx[K], p_my[K], p_yy[K], lo[K], hi[K];
+    T p_gapm_r[UG ? 1 : K], p_xx_r[UG ? 1 : K];
+    __device__ __forceinline__ T p_gapm(int k) const { return p_gapm_r[UG ? 0 : k]; }
+    __device__ __forceinline__ T p_xx(int k) const { return p_xx_r[UG ? 0 : k]; }
+};
+
+template <typename T, int K, bool UG>
+__global__ void __launch_bounds__(kBlockThreads) pairhmm_systolic_kernel(KernelArgs a)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 15u;                                    // lane inside the pair's 16-lane array
+    const uint32_t grp_in_block = threadIdx.x >> 4;                             // 0..15
+    const uint32_t gidx = blockIdx.x * (kBlockThreads / kLanesPerPair) + grp_in_block;
+    const bool valid = gidx < a.n_pairs;
+    const uint32_t pair = a.order[valid ? gidx : 0];
+    const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
+    const uint32_t R = a.read_len[r], H = a.hap_len[h];
+    const uint32_t roff = a.read_off[r];
+    const uint32_t W = planes_words(H);
+    const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
+    const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
+
+    // ---- stage this pair's haplotype planes into LDS (kPlanes * W words, 16 lanes copy) ----
+    uint32_t *pl = lds + grp_in_block * a.lds_words_per_group;
+    {
+        const uint32_t *src = a.planes + a.plane_off[h];
+        for (uint32_t i = lane; i < kPlanes * W; i += kLanesPerPair) pl[i] = src[i];
+    }
+
+    // ---- per-row constants (pairhmm_internal.cpp:466-480 == core/avx512_s.cpp:90-101) ----
+    Rows<T, K, UG> P;
+    T M[K], X[K], Y[K];
+    uint32_t cls_lo = 0, cls_hi = 0;  // 3-bit plane class per row, packed (K <= 16 -> 48 bits)
+    const T init_y = Num<T>::init_const() / static_cast<T>(H);  // rovaca/avx_512_float.cc:32
+    const int pad = kLanesPerPair * K - static_cast<int>(R);    // rows [0, pad) are boundary replicas
+    if (UG) {
+        uint32_t c0 = a.read_gcp[roff] & 127u;
+        P.p_gapm_r[0] = static_cast<T>(1.0) - ph2pr[c0];
+        P.p_xx_r[0] = ph2pr[c0];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int row = static_cast<int>(lane) * K + k - pad;
+        uint32_t cls = 5;
+        if (row >= 0) {
+            const uint32_t at = roff + static_cast<uint32_t>(row);
+            const uint32_t _i = a.read_ins[at] & 127u, _d = a.read_del[at] & 127u, _c = a.read_gcp[at] & 127u,
+                           _q = a.read_qual[at] & 127u;
+            const uint32_t mx = _i > _d ? _i : _d, mn = _i > _d ? _d : _i;
+            P.p_mm[k] = mmtab[((mx * (mx + 1)) >> 1) + mn];  // core/context.h:162-173
+            P.p_mx[k] = ph2pr[_i];
+            P.p_my[k] = ph2pr[_d];
+            P.p_yy[k] = ph2pr[_c];
+            if (!UG) {
+                P.p_gapm_r[UG ? 0 : k] = static_cast<T>(1.0) - ph2pr[_c];
+                P.p_xx_r[UG ? 0 : k] = ph2pr[_c];
+            }
+            const T dist = ph2pr[_q];
+            P.hi[k] = static_cast<T>(1.0) - dist;
+            P.lo[k] = Num<T>::div3(dist);
+            cls = read_class(a.read_bases[at]);
+            M[k] = 0;
+            X[k] = 0;
+            Y[k] = 0;
+        }
+        else {
+            // boundary replica: M = X = 0 and Y = init at every column (prior 0 kills M, p_yy = 1 holds Y)
+            P.p_mm[k] = 0;
+            P.p_mx[k] = 0;
+            P.p_my[k] = 0;
+            P.p_yy[k] = 1;
+            if (!UG) {
+                P.p_gapm_r[UG ? 0 : k] = 0;
+                P.p_xx_r[UG ? 0 : k] = 0;
+            }
+            P.hi[k] = 0;
+            P.lo[k] = 0;
+            M[k] = 0;
+            X[k] = 0;
+            Y[k] = init_y;
+        }
+        if (k < 10)
+            cls_lo |= cls << (3 * k);
+        else
+            cls_hi |= cls << (3 * (k - 10));
+    }
+    __syncthreads();  // planes visible (each group only reads its own, but keep the block-wide fence simple)
+
+    // ---- the sweep ----
+    const uint32_t Tg = valid ? H + (kLanesPerPair - 1) : 0;  // last step of this group
+    uint32_t Tmax = Tg;                                         // wave-uniform loop bound
+    Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+    Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+    Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
+
+    uint32_t mask[K];
+    T dM = 0, dX = 0, dY = init_y;  // row above, previous column (diag for slot 0); lane 0: boundary row
+    T sumM = 0, sumX = 0;
+    const uint32_t wmax = W - 2;
+
+    for (uint32_t t = 1; t <= Tmax; ++t) {
+        if ((t & 31u) == 1u) {
+            // reload every row's 32-column window, starting at this lane's next column
+            const uint32_t jn = t > lane ? t - lane : 1u;  // 1-based
+            uint32_t w = (jn - 1) >> 5;
+            const uint32_t s = (jn - 1) & 31u;
+            w = w < wmax ? w : wmax;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
+                const uint32_t *p = pl + cls * W + w;
+                const uint64_t v = (static_cast<uint64_t>(p[0]) << 32) | p[1];
+                mask[k] = static_cast<uint32_t>((v << s) >> 32);
+            }
+        }
+        const bool act = (t > lane) && (t <= Tg);
+        if (act) {
+            // current column of the row above slot 0: lane-1's last row, or the boundary row in lane 0
+            const T uM0 = dpp_row_shr1(static_cast<T>(0), M[K - 1]);
+            const T uX0 = dpp_row_shr1(static_cast<T>(0), X[K - 1]);
+            const T uY0 = dpp_row_shr1(init_y, Y[K - 1]);
+            T uM = uM0, uX = uX0;     // row above, this column
+            T gM = dM, gX = dX, gY = dY;  // row above, previous column
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                uint32_t nm;
+                const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
+                mask[k] = nm;
+                const T prior = hit ? P.hi[k] : P.lo[k];
+                T tt = gM * P.p_mm[k];
+                tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
+                tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
+                const T nM = tt * prior;
+                const T nX = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
+                const T nY = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my[k]);
+                gM = M[k];
+                gX = X[k];
+                gY = Y[k];
+                M[k] = nM;
+                X[k] = nX;
+                Y[k] = nY;
+                uM = nM;
+                uX = nX;
+            }
+            dM = uM0;
+            dX = uX0;
+            dY = uY0;
+            sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
+            sumX = sumX + X[K - 1];
+        }
+    }
+    if (valid && lane == kLanesPerPair - 1) reinterpret_cast<T *>(a.out_raw)[pair] = sumM + sumX;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// fp64 rescue, first version: one pair per thread, row-major, previous row in a global scratch slab.
+// Same operation order as the fp32 kernels (and as oracle/phmm_oracle.c: phmm_oracle_pair_f64), scale 2^1020.
+// Only pairs whose fp32 sum fell below 1e-28f come here (pairhmm_internal.cpp:578-581).
+// ----------------------------------------------------------------------------------------------------
+__global__ void pairhmm_rescue_f64_kernel(RescueArgs a)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= *a.n_rescue) return;
+    const uint32_t pair = a.rescue_list[g];
+    const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
+    const uint32_t R = a.read_len[r], H = a.hap_len[h];
+    const uint32_t roff = a.read_off[r];
+    const uint8_t *hb = a.hap_bases + a.hap_off[h];
+    double *Mp = a.scratch + static_cast<size_t>(g) * 3 * a.scratch_stride;
+    double *Xp = Mp + a.scratch_stride, *Yp = Xp + a.scratch_stride;
+    const double init_y = __builtin_ldexp(1.0, 1020) / static_cast<double>(H);
+    for (uint32_t j = 0; j <= H; ++j) {
+        Mp[j] = 0.0;
+        Xp[j] = 0.0;
+        Yp[j] = init_y;
+    }
+    for (uint32_t i = 0; i < R; ++i) {
+        const uint32_t at = roff + i;
+        const uint32_t _i = a.read_ins[at] & 127u, _d = a.read_del[at] & 127u, _c = a.read_gcp[at] & 127u,
+                       _q = a.read_qual[at] & 127u;
+        const uint32_t mx = _i > _d ? _i : _d, mn = _i > _d ? _d : _i;
+        const double p_mm = a.mm_table[((mx * (mx + 1)) >> 1) + mn];
+        const double p_gapm = 1.0 - a.ph2pr[_c], p_mx = a.ph2pr[_i], p_xx = a.ph2pr[_c], p_my = a.ph2pr[_d],
+                     p_yy = a.ph2pr[_c];
+        const double dist = a.ph2pr[_q];
+        const double hi = 1.0 - dist, lo = __ddiv_rn(dist, 3.0);
+        const uint8_t rc = a.read_bases[at];
+        const uint32_t rcode = rc == 'A' ? 1u : rc == 'C' ? 2u : rc == 'T' ? 4u : rc == 'G' ? 8u : rc == 'N' ? 15u : 0u;
+        double Md = Mp[0], Xd = Xp[0], Yd = Yp[0], Ml = 0.0, Yl = 0.0;
+        Mp[0] = 0.0;
+        Xp[0] = 0.0;
+        Yp[0] = 0.0;
+        for (uint32_t j = 1; j <= H; ++j) {
+            const double Mu = Mp[j], Xu = Xp[j], Yu = Yp[j];
+            const uint8_t hc = hb[j - 1];
+            const uint32_t hcode = hc == 'A' ? 1u : hc == 'C' ? 2u : hc == 'T' ? 4u : hc == 'G' ? 8u : hc == 'N' ? 15u : 0u;
+            const double prior = (rcode & hcode) ? hi : lo;
+            double tt = Md * p_mm;
+            tt = __builtin_fma(Xd, p_gapm, tt);
+            tt = __builtin_fma(Yd, p_gapm, tt);
+            const double nM = tt * prior;
+            const double nX = __builtin_fma(Xu, p_xx, Mu * p_mx);
+            const double nY = __builtin_fma(Yl, p_yy, Ml * p_my);
+            Md = Mu;
+            Xd = Xu;
+            Yd = Yu;
+            Mp[j] = nM;
+            Xp[j] = nX;
+            Yp[j] = nY;
+            Ml = nM;
+            Yl = nY;
+        }
+    }
+    double sum_m = 0.0, sum_x = 0.0;
+    for (uint32_t j = 1; j <= H; ++j) {
+        sum_m = sum_m + Mp[j];
+        sum_x = sum_x + Xp[j];
+    }
+    a.out_raw64[pair] = sum_m + sum_x;
+}
+
+// fp32 results below the acceptance threshold (rovaca/common.h:9, MIN_ACCEPTED 1e-28f) are queued for fp64
+__global__ void collect_rescue_kernel(const float *__restrict__ raw, uint32_t n_pairs, uint32_t *__restrict__ list,
+                                      uint32_t *__restrict__ count, uint32_t capacity)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    if (raw[p] < 1e-28f) {
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < capacity) list[at] = p;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// launchers (one instantiation per rows-per-lane K)
+// ----------------------------------------------------------------------------------------------------
+template <typename T, int K, bool UG>
+static hipError_t launch_one(const KernelArgs &a, hipStream_t s)
+{
+    const uint32_t groups_per_block = kBlockThreads / kLanesPerPair;
+    const uint32_t blocks = (a.n_pairs + groups_per_block - 1) / groups_per_block;
+    const size_t shmem = static_cast<size_t>(groups_per_block) * a.lds_words_per_group * sizeof(uint32_t);
+    hipLaunchKernelGGL((pairhmm_systolic_kernel<T, K, UG>), dim3(blocks), dim3(kBlockThreads), shmem, s, a);
+    return hipGetLastError();
+}
+
+template <typename T, bool UG, int K>
+static hipError_t launch_k(int k, const KernelArgs &a, hipStream_t s)
+{
+    if (k == K) return launch_one<T, K, UG>(a, s);
+    if constexpr (K < kMaxRowsPerLane)
+        return launch_k<T, UG, K + 1>(k, a, s);
+    else
+        return hipErrorInvalidValue;
+}
+
+hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const KernelArgs &a, hipStream_t s)
+{
+    if (a.n_pairs == 0) return hipSuccess;
+    return uniform_gcp ? launch_k<float, true, 1>(rows_per_lane, a, s) : launch_k<float, false, 1>(rows_per_lane, a, s);
+}
+
+hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
+                             const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,
+                             hipStream_t s)
+{
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(hap_planes_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, hap_bases, hap_off, hap_len,
+                       plane_off, word_owner, n_words, planes);
+    return hipGetLastError();
+}
+
+hipError_t launch_collect_rescue(const float *raw, uint32_t n_pairs, uint32_t *list, uint32_t *count, uint32_t capacity,
+                                 hipStream_t s)
+{
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(collect_rescue_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, raw, n_pairs, list, count,
+                       capacity);
+    return hipGetLastError();
+}
+
+hipError_t launch_rescue_f64(const RescueArgs &a, uint32_t max_rescue, hipStream_t s)
+{
+    if (max_rescue == 0) return hipSuccess;
+    hipLaunchKernelGGL(pairhmm_rescue_f64_kernel, dim3((max_rescue + 63) / 64), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace phmm

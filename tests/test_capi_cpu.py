@@ -1,0 +1,48 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/pairhmm_hip.h declares, builds the
+reference's lookup tables exactly, and refuses to run without a device (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rovaca_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "pairhmm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(phmm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(capi.LIB_PATH)
+    names = _declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/pairhmm_hip.h but not exported"
+    assert set(names) == set(capi.EXPORTS)
+    assert capi.lib().phmm_abi_version() == 1
+
+
+def test_product_tables_equal_reference_tables(golden):
+    t = capi.tables()
+    for k in ("ph2pr_f32", "mm_f32", "ph2pr_f64", "mm_f64"):
+        assert np.array_equal(t[k], golden[k]), k
+
+
+def test_struct_layout_matches_header():
+    # phmm_batch: 2 x u32 + u64 + 12 pointers; phmm_stats: 2 x u64 + 2 x f64 + 2 x u32
+    assert ctypes.sizeof(capi.PhmmBatch) == 16 + 12 * 8
+    assert ctypes.sizeof(capi.PhmmStats) == 40
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(capi.PhmmError, match="no HIP device|no CPU fallback|does not exist"):
+        capi.Engine(0)

@@ -1,0 +1,72 @@
+// ubench_valu.hip -- issue-rate microbenchmark for the VALU instructions the PairHMM kernel is made of (gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_valu tools/ubench_valu.hip ; run on the GPU box.
+// Prints wave-instructions per cycle per SIMD at 1, 2, 4, 8 waves/SIMD (clock measured with s_memtime/s_memrealtime).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+#define REP8(S) S S S S S S S S
+template <int MODE>
+__global__ void k(float* out, int iters, unsigned long long* clk)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b = 0.999f, c = 0.001f;
+    unsigned m0 = threadIdx.x * 2654435761u, m1 = m0 ^ 0x9e3779b9u;
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, db = 0.999, dc = 0.001;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 0) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (MODE == 1) { REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));) }
+        if (MODE == 2) { REP8(asm volatile("v_mul_f32 %0, %0, %8\n v_fmac_f32 %1, %8, %9\n v_mul_f32 %2, %2, %8\n v_fmac_f32 %3, %8, %9\n v_mul_f32 %4, %4, %8\n v_fmac_f32 %5, %8, %9\n v_mul_f32 %6, %6, %8\n v_fmac_f32 %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (MODE == 3) { REP8(asm volatile("s_nop 1\n v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %6 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        if (MODE == 4) { REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %0\n v_cndmask_b32 %2, %8, %9, vcc\n v_add_co_u32 %1, vcc, %1, %1\n v_cndmask_b32 %3, %8, %9, vcc\n v_add_co_u32 %0, vcc, %0, %0\n v_cndmask_b32 %4, %8, %9, vcc\n v_add_co_u32 %1, vcc, %1, %1\n v_cndmask_b32 %5, %8, %9, vcc" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");) }
+        if (MODE == 5) { REP8(asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));) }
+        if (MODE == 6) { REP8(asm volatile("s_nop 1\n v_mul_f32_dpp %0, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_fmac_f32_dpp %2, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mul_f32_dpp %4, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_fmac_f32_dpp %6, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mul_f32_dpp %1, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_fmac_f32_dpp %3, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mul_f32_dpp %5, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_fmac_f32_dpp %7, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (MODE == 7) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(d0 + d1 + d2 + d3) + (float)(m0 + m1);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+template <int MODE> void run(const char* name, float* out, unsigned long long* clk)
+{
+    const int iters = 2000, per_iter = 64;
+    printf("%-34s", name);
+    for (int wps : {1, 2, 4, 8}) {
+        int threads = 256, blocks = 256 * wps;  // 256 CUs x (wps waves/SIMD x 4 SIMD / 4 waves per block)
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, out, 10, clk);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0)); hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, out, iters, clk); CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long h[2]; CHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+        double ghz = (double)h[0] / ((double)h[1] * 10.0);  // memrealtime ticks at 100 MHz
+        double winstr = (double)blocks * 4 * iters * per_iter;
+        double cyc_per_simd = ms * 1e-3 * ghz * 1e9;       // cycles elapsed (each SIMD runs wps waves)
+        double ipc = winstr / (256.0 * 4) / cyc_per_simd;  // wave-instr per cycle per SIMD
+        printf("  w%d: %5.3f ipc (%4.2f cyc/instr, %.2f GHz)", wps, ipc, 1.0 / ipc, ghz);
+    }
+    printf("\n");
+}
+
+int main()
+{
+    float* out; unsigned long long* clk;
+    CHECK(hipMalloc(&out, 256 * 8 * 256 * sizeof(float))); CHECK(hipMalloc(&clk, 16));
+    run<0>("v_fma_f32 (8 indep)", out, clk);
+    run<7>("v_fma_f32 (1 dependent chain)", out, clk);
+    run<1>("v_pk_fma_f32 (4 indep)", out, clk);
+    run<2>("v_mul_f32 / v_fmac_f32", out, clk);
+    run<3>("v_mov_b32_dpp row_shr:1", out, clk);
+    run<6>("v_mul/fmac_f32_dpp row_shr:1", out, clk);
+    run<4>("v_add_co_u32 + v_cndmask_b32", out, clk);
+    run<5>("v_fma_f64 (4 indep)", out, clk);
+    return 0;
+}
