@@ -212,7 +212,9 @@ __global__ void __launch_bounds__(kBlockThreads) pairhmm_systolic_kernel(KernelA
     Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
 
     uint32_t mask[K];
-    T dM = 0, dX = 0, dY = init_y;  // row above, previous column (diag for slot 0); lane 0: boundary row
+    // row above slot 0 at the previous column.  Before the first step that is column 0: Y[0][0] = init when the row
+    // above is the boundary row (lane 0) or a replica of it, and 0 when it is a read row (M[i][0] = X[i][0] = Y[i][0] = 0)
+    T dM = 0, dX = 0, dY = (static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
     T sumM = 0, sumX = 0;
     const uint32_t wmax = W - 2;
 
