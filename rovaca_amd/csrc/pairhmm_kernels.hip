@@ -229,8 +229,8 @@ __global__ void __launch_bounds__(kBlockThreads) pairhmm_systolic_kernel(KernelA
             for (int k = 0; k < K; ++k) {
                 const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
                 const uint32_t *p = pl + cls * W + w;
-                const uint64_t v = (static_cast<uint64_t>(p[0]) << 32) | p[1];
-                mask[k] = static_cast<uint32_t>((v << s) >> 32);
+                const uint32_t w0 = p[0], w1 = p[1];
+                mask[k] = (w0 << s) | ((w1 >> 1) >> (31u - s));  // bits [s, s+32) of w0:w1, MSB first (s = 0..31)
             }
         }
         const bool act = (t > lane) && (t <= Tg);
@@ -239,28 +239,28 @@ __global__ void __launch_bounds__(kBlockThreads) pairhmm_systolic_kernel(KernelA
             const T uM0 = dpp_row_shr1(static_cast<T>(0), M[K - 1]);
             const T uX0 = dpp_row_shr1(static_cast<T>(0), X[K - 1]);
             const T uY0 = dpp_row_shr1(init_y, Y[K - 1]);
-            T uM = uM0, uX = uX0;     // row above, this column
-            T gM = dM, gX = dX, gY = dY;  // row above, previous column
+            // Pass 1, bottom row first: Y' and M' read only the previous anti-diagonal, so walking upwards lets every
+            // value be overwritten in place (row k's old M/X/Y are last read by row k+1, which is already done).
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
+            for (int k = K - 1; k >= 0; --k) {
                 uint32_t nm;
                 const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
                 mask[k] = nm;
                 const T prior = hit ? P.hi[k] : P.lo[k];
+                Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my[k]);
+                const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
                 T tt = gM * P.p_mm[k];
                 tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
                 tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
-                const T nM = tt * prior;
-                const T nX = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
-                const T nY = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my[k]);
-                gM = M[k];
-                gX = X[k];
-                gY = Y[k];
-                M[k] = nM;
-                X[k] = nX;
-                Y[k] = nY;
-                uM = nM;
-                uX = nX;
+                M[k] = tt * prior;
+            }
+            // Pass 2, top row first: the insertion state chains down the column through the NEW M and X.
+            T uM = uM0, uX = uX0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                X[k] = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
+                uM = M[k];
+                uX = X[k];
             }
             dM = uM0;
             dX = uX0;
