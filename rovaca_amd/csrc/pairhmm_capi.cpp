@@ -281,14 +281,16 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
     }
     rb->cells = cells;
 
-    // uniform gap-continuation penalty (the Rovaca case) selects the kernel variant with shared p_gapm / p_xx
+    // the Rovaca case -- one gap-continuation penalty for every base and deletion gap-open == insertion gap-open
+    // (read_record.cpp:205-210, pairhmm_internal.cpp:425) -- selects the kernel variant that shares those constants
     bool ug = read_bytes > 0;
     {
         const uint8_t c0 = read_bytes ? (b->read_gcp[b->read_off[0]] & 127) : 0;
         for (uint32_t r = 0; r < b->n_reads && ug; ++r) {
             const uint8_t *g = b->read_gcp + b->read_off[r];
+            const uint8_t *gi = b->read_ins + b->read_off[r], *gd = b->read_del + b->read_off[r];
             for (uint32_t i = 0; i < b->read_len[r]; ++i)
-                if ((g[i] & 127) != c0) {
+                if ((g[i] & 127) != c0 || ((gi[i] ^ gd[i]) & 127)) {
                     ug = false;
                     break;
                 }

@@ -114,10 +114,13 @@ __global__ void hap_planes_kernel(const uint8_t *__restrict__ hap_bases, const u
 template <typename T, int K, bool UG>
 struct Rows
 {
-    // per-row constants.  UG ("uniform gap continuation", the Rovaca case: read_record.cpp:205-210 fixes gcp = 10)
-    // shares p_gapm and p_xx across rows; p_yy stays per row because a padding row needs p_yy = 1.
-    T p_mm[K], p_mx[K], p_my[K], p_yy[K], lo[K], hi[K];
+    // per-row constants.  UG is the Rovaca case: the gap-continuation penalty is one constant (read_record.cpp:205-210
+    // fixes gcp = 10) and the deletion gap-open array is the insertion one (pairhmm_internal.cpp:425), so p_gapm and
+    // p_xx are shared by all rows and p_my is p_mx.  p_yy stays per row because a padding row needs p_yy = 1.
+    T p_mm[K], p_mx[K], p_yy[K], lo[K], hi[K];
+    T p_my_r[UG ? 1 : K];
     T p_gapm_r[UG ? 1 : K], p_xx_r[UG ? 1 : K];
+    __device__ __forceinline__ T p_my(int k) const { return UG ? p_mx[k] : p_my_r[UG ? 0 : k]; }
     __device__ __forceinline__ T p_gapm(int k) const { return p_gapm_r[UG ? 0 : k]; }
     __device__ __forceinline__ T p_xx(int k) const { return p_xx_r[UG ? 0 : k]; }
 };
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(kBlockThreads) pairhmm_systolic_kernel(KernelA
             const uint32_t mx = _i > _d ? _i : _d, mn = _i > _d ? _d : _i;
             P.p_mm[k] = mmtab[((mx * (mx + 1)) >> 1) + mn];  // core/context.h:162-173
             P.p_mx[k] = ph2pr[_i];
-            P.p_my[k] = ph2pr[_d];
+            if (!UG) P.p_my_r[UG ? 0 : k] = ph2pr[_d];
             P.p_yy[k] = ph2pr[_c];
             if (!UG) {
                 P.p_gapm_r[UG ? 0 : k] = static_cast<T>(1.0) - ph2pr[_c];
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(kBlockThreads) pairhmm_systolic_kernel(KernelA
             // boundary replica: M = X = 0 and Y = init at every column (prior 0 kills M, p_yy = 1 holds Y)
             P.p_mm[k] = 0;
             P.p_mx[k] = 0;
-            P.p_my[k] = 0;
+            if (!UG) P.p_my_r[UG ? 0 : k] = 0;
             P.p_yy[k] = 1;
             if (!UG) {
                 P.p_gapm_r[UG ? 0 : k] = 0;
@@ -211,63 +214,102 @@ __global__ void __launch_bounds__(kBlockThreads) pairhmm_systolic_kernel(KernelA
     Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
     Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
 
+    uint32_t Tmin = Tg;  // until here every lane of the wave is busy once the pipeline is full
+    Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+    Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
+    Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
+
     uint32_t mask[K];
-    // row above slot 0 at the previous column.  Before the first step that is column 0: Y[0][0] = init when the row
-    // above is the boundary row (lane 0) or a replica of it, and 0 when it is a read row (M[i][0] = X[i][0] = Y[i][0] = 0)
-    T dM = 0, dX = 0, dY = (static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
+    // The row above slot 0 travels between lanes in two register sets that swap roles every step: one holds that
+    // row at the current column (written by the DPP shift of this step), the other at the previous column (written
+    // one step earlier).  Lane 0 never receives anything, so its copies keep the boundary row (0, 0, init) for ever;
+    // the DPP's `old` operand is the destination itself, which costs no instruction.  Before a lane's first step
+    // both sets hold column 0 of the row above: Y[0][0] = init when that row is the boundary row or a replica of it
+    // (lane * K <= pad), and 0 when it is a read row (M[i][0] = X[i][0] = Y[i][0] = 0).
+    const T y_col0 = (static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
+    T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
     T sumM = 0, sumX = 0;
     const uint32_t wmax = W - 2;
 
-    for (uint32_t t = 1; t <= Tmax; ++t) {
-        if ((t & 31u) == 1u) {
-            // reload every row's 32-column window, starting at this lane's next column
-            const uint32_t jn = t > lane ? t - lane : 1u;  // 1-based
-            uint32_t w = (jn - 1) >> 5;
-            const uint32_t s = (jn - 1) & 31u;
-            w = w < wmax ? w : wmax;
+    auto reload = [&](uint32_t t) {
+        // every row's 32-column window of its match plane, starting at this lane's next column
+        const uint32_t jn = t > lane ? t - lane : 1u;  // 1-based
+        uint32_t w = (jn - 1) >> 5;
+        const uint32_t s = (jn - 1) & 31u;
+        w = w < wmax ? w : wmax;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
-                const uint32_t *p = pl + cls * W + w;
-                const uint32_t w0 = p[0], w1 = p[1];
-                mask[k] = (w0 << s) | ((w1 >> 1) >> (31u - s));  // bits [s, s+32) of w0:w1, MSB first (s = 0..31)
-            }
+        for (int k = 0; k < K; ++k) {
+            const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
+            const uint32_t *p = pl + cls * W + w;
+            const uint32_t w0 = p[0], w1 = p[1];
+            mask[k] = (w0 << s) | ((w1 >> 1) >> (31u - s));  // bits [s, s+32) of w0:w1, MSB first (s = 0..31)
         }
-        const bool act = (t > lane) && (t <= Tg);
-        if (act) {
-            // current column of the row above slot 0: lane-1's last row, or the boundary row in lane 0
-            const T uM0 = dpp_row_shr1(static_cast<T>(0), M[K - 1]);
-            const T uX0 = dpp_row_shr1(static_cast<T>(0), X[K - 1]);
-            const T uY0 = dpp_row_shr1(init_y, Y[K - 1]);
-            // Pass 1, bottom row first: Y' and M' read only the previous anti-diagonal, so walking upwards lets every
-            // value be overwritten in place (row k's old M/X/Y are last read by row k+1, which is already done).
+    };
+
+    // one anti-diagonal.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it at this column.
+    auto step = [&](T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
+        uM0 = dpp_row_shr1(uM0, M[K - 1]);
+        uX0 = dpp_row_shr1(uX0, X[K - 1]);
+        uY0 = dpp_row_shr1(uY0, Y[K - 1]);
+        // Pass 1, bottom row first: Y' and M' read only the previous anti-diagonal, so walking upwards lets every
+        // value be overwritten in place (row k's old M/X/Y are last read by row k+1, which is already done).
 #pragma unroll
-            for (int k = K - 1; k >= 0; --k) {
-                uint32_t nm;
-                const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
-                mask[k] = nm;
-                const T prior = hit ? P.hi[k] : P.lo[k];
-                Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my[k]);
-                const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
-                T tt = gM * P.p_mm[k];
-                tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
-                tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
-                M[k] = tt * prior;
-            }
-            // Pass 2, top row first: the insertion state chains down the column through the NEW M and X.
-            T uM = uM0, uX = uX0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                X[k] = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
-                uM = M[k];
-                uX = X[k];
-            }
-            dM = uM0;
-            dX = uX0;
-            dY = uY0;
-            sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
-            sumX = sumX + X[K - 1];
+        for (int k = K - 1; k >= 0; --k) {
+            uint32_t nm;
+            const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
+            mask[k] = nm;
+            const T prior = hit ? P.hi[k] : P.lo[k];
+            Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my(k));
+            const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
+            T tt = gM * P.p_mm[k];
+            tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
+            tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
+            M[k] = tt * prior;
         }
+        // Pass 2, top row first: the insertion state chains down the column through the NEW M and X.
+        T uM = uM0, uX = uX0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            X[k] = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
+            uM = M[k];
+            uX = X[k];
+        }
+        sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
+        sumX = sumX + X[K - 1];
+    };
+    auto step_t = [&](uint32_t t) {
+        if (t & 1u)
+            step(aM, aX, aY, bM, bX, bY);
+        else
+            step(bM, bX, bY, aM, aX, aY);
+    };
+
+    uint32_t t = 1;
+    // fill: lane l starts at step l + 1
+    const uint32_t Tfill = Tmax < (uint32_t)(kLanesPerPair - 1) ? Tmax : (uint32_t)(kLanesPerPair - 1);
+    for (; t <= Tfill; ++t) {
+        if ((t & 31u) == 1u) reload(t);
+        if ((t > lane) && (t <= Tg)) step_t(t);
+    }
+    // steady state: every lane of all four pairs has work, no per-lane predicate
+    if (t <= Tmin && !(t & 1u)) {
+        step(bM, bX, bY, aM, aX, aY);
+        ++t;
+    }
+    for (; t + 1 <= Tmin; t += 2) {  // t is odd here: the two register sets swap roles without a single move
+        if ((t & 31u) == 1u) reload(t);
+        step(aM, aX, aY, bM, bX, bY);
+        step(bM, bX, bY, aM, aX, aY);
+    }
+    if (t <= Tmin) {
+        if ((t & 31u) == 1u) reload(t);
+        step(aM, aX, aY, bM, bX, bY);
+        ++t;
+    }
+    // drain: pairs with a shorter haplotype than the longest of the wave drop out group by group
+    for (; t <= Tmax; ++t) {
+        if ((t & 31u) == 1u) reload(t);
+        if (t <= Tg) step_t(t);
     }
     if (valid && lane == kLanesPerPair - 1) reinterpret_cast<T *>(a.out_raw)[pair] = sumM + sumX;
 }
