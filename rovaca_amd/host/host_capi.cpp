@@ -1,0 +1,72 @@
+// host_capi.cpp -- plain-C entry points over the C++ host adapter, so that it can be driven without Rovaca's types
+// (the Python tests, other FFI users).  One call = one region = one rovaca::call_pairhmm invocation.
+#include <cmath>
+#include <cstring>
+#include <memory_resource>
+#include <vector>
+
+#include "pairhmm_gpu_engine.h"
+#include "pairhmm_host_logic.h"
+
+extern "C" {
+
+// host logic, exposed for CPU-side parity tests (no device involved)
+void rovaca_amd_modify_read_qualities(uint8_t *qual, uint32_t n, uint8_t mapq, int32_t min_q)
+{
+    rovaca_amd::modify_read_qualities(qual, n, mapq, min_q);
+}
+int32_t rovaca_amd_tandem_repeat_length(const uint8_t *bases, uint32_t n, uint32_t offset)
+{
+    return rovaca_amd::tandem_repeat_length(bases, n, offset);
+}
+void rovaca_amd_apply_pcr_error_model(const uint8_t *bases, uint8_t *gap_open, uint32_t n, int model)
+{
+    rovaca_amd::apply_pcr_error_model(bases, gap_open, n, model);
+}
+void rovaca_amd_normalize_likelihoods(double *lik, uint32_t n_reads, uint32_t n_haps)
+{
+    rovaca_amd::normalize_likelihoods(lik, n_reads, n_haps);
+}
+uint32_t rovaca_amd_poorly_modelled_reads(const double *lik, const int32_t *read_len, uint32_t n_reads, uint32_t n_haps,
+                                          uint8_t *drop)
+{
+    std::vector<size_t> d = rovaca_amd::poorly_modelled_reads(lik, read_len, n_reads, n_haps);
+    memset(drop, 0, n_reads);
+    for (size_t r : d) drop[r] = 1;
+    return (uint32_t)d.size();
+}
+
+// 1 when an MI355X engine was installed into rovaca::call_pairhmm, 0 when no device is visible
+int rovaca_amd_init_pairhmm_ptr_gpu(int device_id) { return rovaca::init_pairhmm_ptr_gpu(device_id) ? 1 : 0; }
+
+// One region through rovaca::call_pairhmm (must have been installed).  Inputs are raw BAM-style reads (bases, quals,
+// mapping quality) and haplotype strings; out_hap_read is [n_haps][n_reads] (tail NaN), survivors[k] the original index
+// of the k-th read left in the read vector.  Returns the number of surviving reads, or -1 if the engine is not installed.
+int32_t rovaca_amd_call_region(const uint8_t *read_bases, const uint8_t *read_qual, const uint32_t *read_off,
+                               const uint32_t *read_len, const uint8_t *read_mq, uint32_t n_reads, const uint8_t *hap_bases,
+                               const uint32_t *hap_off, const uint32_t *hap_len, uint32_t n_haps, int32_t min_quality_threshold,
+                               int pcr_model, double *out_hap_read, uint32_t *survivors)
+{
+    using namespace rovaca;
+    if (!call_pairhmm) return -1;
+    std::pmr::monotonic_buffer_resource arena;  // stands in for the per-region RovacaMemoryPool
+    std::vector<ReadRecord> reads;
+    std::vector<Haplotype> haps;
+    reads.reserve(n_reads);
+    haps.reserve(n_haps);
+    for (uint32_t r = 0; r < n_reads; ++r)
+        reads.emplace_back(read_bases + read_off[r], read_qual + read_off[r], read_len[r], read_mq[r]);
+    for (uint32_t h = 0; h < n_haps; ++h) haps.emplace_back(hap_bases + hap_off[h], hap_len[h]);
+    ReadVector rs{&arena};
+    HaplotypeVector hs{&arena};
+    for (auto &r : reads) rs.push_back(&r);
+    for (auto &h : haps) hs.push_back(&h);
+    DoubleVector2D lik = call_pairhmm(hs, rs, min_quality_threshold, static_cast<PcrIndelModel>(pcr_model), &arena);
+    for (size_t k = 0; k < (size_t)n_haps * n_reads; ++k) out_hap_read[k] = NAN;
+    for (size_t h = 0; h < lik.size(); ++h)
+        for (size_t k = 0; k < lik[h].size(); ++k) out_hap_read[h * n_reads + k] = lik[h][k];
+    for (size_t k = 0; k < rs.size(); ++k) survivors[k] = (uint32_t)(rs[k] - reads.data());
+    return (int32_t)rs.size();
+}
+
+}  // extern "C"

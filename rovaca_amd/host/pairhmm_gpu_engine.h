@@ -1,0 +1,44 @@
+// pairhmm_gpu_engine.h -- the MI355X candidate for Rovaca's PairHMM seam.
+//
+// The reference selects its likelihood engine once, in rovaca::init_pairhmm_ptr (pairhmm/pairhmm_engine.cpp:21-53), by
+// assigning the process-global function pointer rovaca::call_pairhmm (pairhmm/pairhmm_engine.h:14-15).  This header
+// declares a third candidate with the identical C++ signature, plus the init hook that installs it.  See
+// INTEGRATION.md for the patch to pairhmm_engine.cpp.
+#ifndef ROVACA_AMD_PAIRHMM_GPU_ENGINE_H_
+#define ROVACA_AMD_PAIRHMM_GPU_ENGINE_H_
+
+#ifdef ROVACA_AMD_IN_ROVACA_TREE
+#include "../common/enum.h"
+#include "../genotype/forward.h"
+#else
+#include "rovaca_seam.h"
+#endif
+
+namespace rovaca
+{
+
+// Same contract as call_old_pairhmm / call_new_pairhmm002 (pairhmm/pairhmm_internal.cpp:505-594, :596-753):
+//   * empty hs or rs -> {} (:508-510);
+//   * returns [hap][read] log10 likelihoods allocated from `pool`, row width = the ORIGINAL read count, valid prefix =
+//     surviving reads, tail NaN (:516, :589-593);
+//   * `rs` is mutated: poorly modelled reads are erased in place (:161-182) and the caller uses the shrunken list;
+//   * reads need not be sorted by length (the AVX-512 driver requires it, :602; this engine bins by length itself);
+//   * callable concurrently from many worker threads (haplotypecaller_engine.cpp:119): each thread gets its own device
+//     context (stream + staging) on first use.
+DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32_t min_quality_threshold,
+                                PcrIndelModel pcr_option, pMemoryPool pool);
+
+// Mirrors the seam's global: what haplotypecaller_engine.cpp:250 calls.
+extern DoubleVector2D (*call_pairhmm)(const HaplotypeVector &hs, ReadVector &rs, int32_t min_quality_threshold,
+                                      PcrIndelModel pcr_option, pMemoryPool pool);
+
+// Installs call_gpu_pairhmm into call_pairhmm.  Returns false (and leaves the pointer alone) when no MI355X is visible,
+// so that the reference's init_pairhmm_ptr can fall through to its AVX selection; it never substitutes a CPU path of its
+// own.  `device_id` < 0 means round-robin over all visible devices per calling thread.
+bool init_pairhmm_ptr_gpu(int device_id = -1);
+
+// true once init_pairhmm_ptr_gpu succeeded (the caller skips its AVX-512 read pre-sort, haplotypecaller_engine.cpp:245-248)
+bool gpu_pairhmm_active();
+
+}  // namespace rovaca
+#endif

@@ -1,0 +1,36 @@
+// pairhmm_host_logic.h -- the integer / table work the reference does on the host around its PairHMM kernels
+// (SURVEY.md rows H3, H4, H8), as free functions over plain buffers.  Product code (never the oracle).
+#ifndef ROVACA_AMD_PAIRHMM_HOST_LOGIC_H_
+#define ROVACA_AMD_PAIRHMM_HOST_LOGIC_H_
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace rovaca_amd
+{
+
+// adapter.h:5-7, :20-23
+constexpr uint8_t kMinQuality = 6;
+constexpr int kMaxRepeatLength = 20;
+constexpr int kMaxStrUnitLength = 8;
+constexpr uint8_t kDefaultGapOpen = '-';      // 45, read_record.cpp:191-196
+constexpr uint8_t kDefaultGapCont = '+' - 33;  // 10, read_record.cpp:205-210
+constexpr double kLog10QualityPerBase = -4.0;
+constexpr double kExpectedErrorRatePerBase = 0.02;
+constexpr double kMaximumExpectedErrorPerRead = 2.0;
+constexpr double kMaximumBestAltLikelihoodDifference = -4.5;
+
+// H3  pairhmm_internal.cpp:434-439: q = min(q, MQ); q < threshold -> 6
+void modify_read_qualities(uint8_t *qual, uint32_t n, uint8_t mapping_quality, int32_t min_quality_threshold);
+
+// H4  pairhmm_internal.cpp:65-119 / :195-229 / :121-159.  model: 0 NONE, 1 HOSTILE, 2 AGGRESSIVE, 3 CONSERVATIVE
+int32_t tandem_repeat_length(const uint8_t *bases, uint32_t n, uint32_t offset);
+void apply_pcr_error_model(const uint8_t *bases, uint8_t *gap_open, uint32_t n, int model);
+
+// H8  pairhmm_internal.cpp:53-63 and :161-182 on a row-major [n_reads][n_haps] matrix
+void normalize_likelihoods(double *lik, size_t n_reads, size_t n_haps);
+// returns indices of reads to DROP, ascending
+std::vector<size_t> poorly_modelled_reads(const double *lik, const int32_t *read_len, size_t n_reads, size_t n_haps);
+
+}  // namespace rovaca_amd
+#endif

@@ -1,0 +1,70 @@
+"""ctypes binding of the C++ host adapter (rovaca_amd/lib/librovaca_pairhmm_host.so): the rovaca::call_pairhmm mirror
+and the host logic around the kernels (quality modification, PCR indel model, normalisation, read filter)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librovaca_pairhmm_host.so")
+_LIB = None
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+PCR = {"NONE": 0, "HOSTILE": 1, "AGGRESSIVE": 2, "CONSERVATIVE": 3}  # common/enum.h:8
+
+EXPORTS = ("rovaca_amd_modify_read_qualities", "rovaca_amd_tandem_repeat_length", "rovaca_amd_apply_pcr_error_model",
+           "rovaca_amd_normalize_likelihoods", "rovaca_amd_poorly_modelled_reads", "rovaca_amd_init_pairhmm_ptr_gpu",
+           "rovaca_amd_call_region")
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+    L = C.CDLL(LIB_PATH)
+    L.rovaca_amd_modify_read_qualities.argtypes = [u8p, C.c_uint32, C.c_uint8, C.c_int32]
+    L.rovaca_amd_modify_read_qualities.restype = None
+    L.rovaca_amd_tandem_repeat_length.argtypes = [u8p, C.c_uint32, C.c_uint32]
+    L.rovaca_amd_tandem_repeat_length.restype = C.c_int32
+    L.rovaca_amd_apply_pcr_error_model.argtypes = [u8p, u8p, C.c_uint32, C.c_int]
+    L.rovaca_amd_apply_pcr_error_model.restype = None
+    L.rovaca_amd_normalize_likelihoods.argtypes = [f64p, C.c_uint32, C.c_uint32]
+    L.rovaca_amd_normalize_likelihoods.restype = None
+    L.rovaca_amd_poorly_modelled_reads.argtypes = [f64p, i32p, C.c_uint32, C.c_uint32, u8p]
+    L.rovaca_amd_poorly_modelled_reads.restype = C.c_uint32
+    L.rovaca_amd_init_pairhmm_ptr_gpu.argtypes = [C.c_int]
+    L.rovaca_amd_init_pairhmm_ptr_gpu.restype = C.c_int
+    L.rovaca_amd_call_region.argtypes = [u8p, u8p, u32p, u32p, u8p, C.c_uint32, u8p, u32p, u32p, C.c_uint32, C.c_int32,
+                                         C.c_int, f64p, u32p]
+    L.rovaca_amd_call_region.restype = C.c_int32
+    _LIB = L
+    return L
+
+
+def init_pairhmm_ptr_gpu(device=-1):
+    """Install the MI355X engine into rovaca::call_pairhmm.  False when no device is visible."""
+    return bool(lib().rovaca_amd_init_pairhmm_ptr_gpu(int(device)))
+
+
+def call_region(read_bases, read_qual, read_off, read_len, read_mq, hap_bases, hap_off, hap_len, min_quality_threshold=18,
+                pcr_model="CONSERVATIVE"):
+    """One region through rovaca::call_pairhmm.  Returns (matrix [n_haps][n_reads], survivors)."""
+    L = lib()
+    n_reads, n_haps = len(read_len), len(hap_len)
+    out = np.full((n_haps, n_reads), np.nan)
+    surv = np.zeros(max(n_reads, 1), np.uint32)
+    n = L.rovaca_amd_call_region(np.ascontiguousarray(read_bases, np.uint8), np.ascontiguousarray(read_qual, np.uint8),
+                                 np.ascontiguousarray(read_off, np.uint32), np.ascontiguousarray(read_len, np.uint32),
+                                 np.ascontiguousarray(read_mq, np.uint8), n_reads, np.ascontiguousarray(hap_bases, np.uint8),
+                                 np.ascontiguousarray(hap_off, np.uint32), np.ascontiguousarray(hap_len, np.uint32), n_haps,
+                                 int(min_quality_threshold), PCR[pcr_model] if isinstance(pcr_model, str) else int(pcr_model),
+                                 out.reshape(-1), surv)
+    if n < 0:
+        raise RuntimeError("rovaca::call_pairhmm is not installed: init_pairhmm_ptr_gpu() found no device")
+    return out, surv[:n].copy()

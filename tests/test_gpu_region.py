@@ -1,0 +1,71 @@
+"""The drop-in adapter end to end on the GPU: rovaca::call_pairhmm (C++ host code over the C ABI) against the oracle's
+restatement of call_old_pairhmm / call_new_pairhmm002 (pairhmm_internal.cpp:505-753), including the in/out mutation of
+the read vector and the [hap][read] layout with NaN tail."""
+import numpy as np
+import pytest
+
+import oracle
+from rovaca_amd import hostapi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_region(seed, reads, haps, read_len, hap_len, sub_rate=0.01, bad_reads=0):
+    rng = np.random.default_rng(seed)
+    b = synth.make_batch(seed=seed, n_regions=1, reads=reads, haps=haps, read_len=read_len, hap_len=hap_len, sub_rate=sub_rate)
+    n = b.read_bases.shape[0]
+    qual = rng.choice(np.array([2, 11, 25, 37, 41], np.uint8), n, p=[0.02, 0.05, 0.15, 0.7, 0.08])  # raw BAM quals
+    mq = rng.choice(np.array([60, 60, 60, 29, 12], np.uint8), b.n_reads)
+    bases = b.read_bases.copy()
+    for r in rng.choice(b.n_reads, bad_reads, replace=False):  # unrelated reads: must be filtered out (H8)
+        o, L = int(b.read_off[r]), int(b.read_len[r])
+        bases[o:o + L] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)]
+    return bases, qual, b.read_off, b.read_len, mq, b.hap_bases, b.hap_off, b.hap_len
+
+
+@pytest.fixture(scope="module", autouse=True)
+def installed():
+    assert hostapi.init_pairhmm_ptr_gpu(0)
+
+
+@pytest.mark.parametrize("model", ["NONE", "CONSERVATIVE", "HOSTILE"])
+def test_region_matches_oracle(model):
+    args = _raw_region(21, reads=48, haps=9, read_len=(60, 151), hap_len=320, bad_reads=5)
+    got, surv = hostapi.call_region(*args, min_quality_threshold=18, pcr_model=model)
+    n_reads, n_haps = len(args[3]), len(args[7])
+    want = np.full(n_haps * n_reads, np.nan)
+    wsurv = np.zeros(n_reads, np.uint32)
+    k = oracle.lib().phmm_oracle_call_region(args[0], args[1], args[2], args[3], args[4], n_reads, args[5], args[6], args[7],
+                                             n_haps, 18, hostapi.PCR[model], want, wsurv)
+    want = want.reshape(n_haps, n_reads)
+    assert len(surv) == k and np.array_equal(surv, wsurv[:k])
+    assert k < n_reads  # the unrelated reads were dropped
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[:, :k], want[:, :k])  # fp32 path bit-identical, rescued pairs capped to best - 4.5
+    assert np.all(np.isnan(got[:, k:]))
+
+
+def test_small_region_and_empty_inputs():
+    args = _raw_region(22, reads=3, haps=2, read_len=40, hap_len=70)
+    got, surv = hostapi.call_region(*args)
+    assert got.shape == (2, 3) and len(surv) == 3 and np.all(np.isfinite(got))
+    e8, e32 = np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+    got, surv = hostapi.call_region(e8, e8, e32, e32, e8, args[5], args[6], args[7])  # no reads -> {} (:508-510)
+    assert got.shape == (2, 0) and len(surv) == 0
+
+
+def test_concurrent_workers():
+    # the caller runs this path from many asio workers at once (haplotypecaller_engine.cpp:119)
+    import threading
+    regions = [_raw_region(30 + i, reads=20, haps=5, read_len=(50, 150), hap_len=260) for i in range(8)]
+    single = [hostapi.call_region(*r) for r in regions]
+    out = [None] * len(regions)
+
+    def work(i):
+        out[i] = hostapi.call_region(*regions[i])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(regions))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for (a, sa), (b, sb) in zip(single, out):
+        assert np.array_equal(sa, sb) and np.array_equal(a, b, equal_nan=True)
