@@ -125,8 +125,12 @@ struct Rows
     __device__ __forceinline__ T p_xx(int k) const { return p_xx_r[UG ? 0 : k]; }
 };
 
+// Occupancy target (waves per SIMD) handed to the register allocator: the UG kernel at K = 10 (150-bp reads) needs
+// 131 VGPRs unconstrained, 3 more than the 128 that admit a fourth wave.
+#define PHMM_MIN_WAVES(K, UG) (((UG) && (K) <= 10) ? 4 : 1)
+
 template <typename T, int K, bool UG>
-__global__ void __launch_bounds__(kBlockThreads) pairhmm_systolic_kernel(KernelArgs a)
+__global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_systolic_kernel(KernelArgs a)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & 15u;                                    // lane inside the pair's 16-lane array

@@ -16,8 +16,11 @@
 namespace rovaca
 {
 
+#ifndef ROVACA_AMD_IN_ROVACA_TREE
+// stand-alone build: this library owns the seam's global.  Inside Rovaca it is defined at pairhmm_engine.cpp:16-17.
 DoubleVector2D (*call_pairhmm)(const HaplotypeVector &hs, ReadVector &rs, int32_t min_quality_threshold,
                                PcrIndelModel pcr_option, pMemoryPool pool) = nullptr;
+#endif
 
 namespace
 {
