@@ -80,10 +80,16 @@ struct phmm_context
 
 struct Bin
 {
-    int rows_per_lane;
+    int rows_per_lane;      // 1..16: single-pass kernel <K>; 0: striped kernel (long read or long haplotype)
     uint32_t first, count;  // range of `order`
     uint32_t lds_words_per_group;
+    uint32_t max_hap_len;
 };
+
+// single-pass kernels keep 16 pairs' haplotype planes in LDS per workgroup; longer haplotypes take the striped kernel
+constexpr uint32_t kSinglePassMaxHap = 4096;
+constexpr uint32_t kMaxLen = 1u << 20;
+constexpr uint32_t kStripedMaxBlocks = 1024;  // resident groups that own a carry row: 4 per block
 
 struct phmm_resident
 {
@@ -96,8 +102,8 @@ struct phmm_resident
     DevBuf<float> raw32;
     DevBuf<double> raw64;
     DevBuf<uint32_t> rescue_list, rescue_count;
-    DevBuf<double> scratch;
-    uint32_t scratch_pairs = 0;
+    DevBuf<float> carry32;
+    DevBuf<double> carry64;
     std::vector<Bin> bins;
     uint32_t last_rescued = 0;
     double last_kernel_ms = 0.0;
@@ -221,9 +227,10 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
         hap_bytes = std::max<uint64_t>(hap_bytes, (uint64_t)b->hap_off[h] + b->hap_len[h]);
         max_hap = std::max(max_hap, b->hap_len[h]);
     }
-    if (max_read > (uint32_t)(phmm::kLanesPerPair * phmm::kMaxRowsPerLane))
-        return fail(PHMM_E_INVALID, "phmm_upload: read of %u bases exceeds the %d-row single-pass kernel", max_read,
-                    phmm::kLanesPerPair * phmm::kMaxRowsPerLane);
+    if (max_read > kMaxLen || max_hap > kMaxLen)
+        return fail(PHMM_E_INVALID, "phmm_upload: sequence longer than %u bases", kMaxLen);
+    if ((uint64_t)phmm::kStripedGroupsPerBlock * phmm::striped_lds_words(max_hap, 8) * sizeof(uint32_t) > 64u * 1024u)
+        return fail(PHMM_E_INVALID, "phmm_upload: haplotype of %u bases exceeds the LDS plane budget", max_hap);
 
     phmm_resident *rb = new (std::nothrow) phmm_resident();
     if (!rb) return fail(PHMM_E_NOMEM, "phmm_upload: out of host memory");
@@ -253,30 +260,39 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
             ph[p] = b->pair_hap[p];
         }
     }
-    // key = (rows per lane, haplotype length): one launch per rows-per-lane value, waves of near-equal sweep length
+    // key = (rows per lane, haplotype length): one launch per rows-per-lane value, waves of near-equal sweep length.
+    // Pairs with a read above 256 bases or a haplotype above the single-pass LDS budget go to the striped kernel
+    // (class 17 here), ordered by (number of stripes, haplotype length).
     std::vector<uint64_t> keys(n_pairs);
     uint64_t cells = 0;
     for (uint64_t p = 0; p < n_pairs; ++p) {
         const uint32_t R = b->read_len[pr[p]], H = b->hap_len[ph[p]];
-        const uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
+        uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
         cells += (uint64_t)R * H;
-        keys[p] = ((uint64_t)K << 56) | ((uint64_t)H << 32) | p;
+        if (K > (uint32_t)phmm::kMaxRowsPerLane || H > kSinglePassMaxHap) {
+            const uint32_t S = phmm::kLanesPerPair * phmm::kStripedRowsF32;
+            const uint64_t stripes = std::min<uint64_t>((R + S - 1) / S, 63u);
+            keys[p] = (17ull << 58) | (stripes << 52) | ((uint64_t)H << 32) | p;  // H < 2^20
+        }
+        else {
+            keys[p] = ((uint64_t)K << 58) | ((uint64_t)H << 32) | p;
+        }
     }
     std::sort(keys.begin(), keys.end());
     std::vector<uint32_t> order(n_pairs);
     for (uint64_t i = 0; i < n_pairs; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
     for (uint64_t i = 0; i < n_pairs;) {
-        const int K = (int)(keys[i] >> 56);
+        const int cls = (int)(keys[i] >> 58);
         uint64_t j = i;
         uint32_t hmax = 0;
-        while (j < n_pairs && (int)(keys[j] >> 56) == K) {
-            hmax = std::max(hmax, (uint32_t)((keys[j] >> 32) & 0xFFFFFFu));
+        while (j < n_pairs && (int)(keys[j] >> 58) == cls) {
+            hmax = std::max(hmax, b->hap_len[ph[order[j]]]);
             ++j;
         }
-        const uint32_t lds_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
-        if ((uint64_t)lds_words * (phmm::kBlockThreads / phmm::kLanesPerPair) * sizeof(uint32_t) > 64u * 1024u)
-            return fail(PHMM_E_INVALID, "phmm_upload: haplotype of %u bases exceeds the LDS plane budget of this kernel", hmax);
-        rb->bins.push_back(Bin{K, (uint32_t)i, (uint32_t)(j - i), lds_words});
+        if (cls == 17)
+            rb->bins.push_back(Bin{0, (uint32_t)i, (uint32_t)(j - i), phmm::striped_lds_words(hmax, 4), hmax});
+        else
+            rb->bins.push_back(Bin{cls, (uint32_t)i, (uint32_t)(j - i), (uint32_t)phmm::kPlanes * phmm::planes_words(hmax), hmax});
         i = j;
     }
     rb->cells = cells;
@@ -368,7 +384,16 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.ph2pr = c->ph2pr_f32.p;
         a.mm_table = c->mm_f32.p;
         a.out_raw = rb->raw32.p;
-        HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, c->stream));
+        if (bin.rows_per_lane > 0) {
+            HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, c->stream));
+        }
+        else {
+            const uint32_t blocks = std::min<uint32_t>((bin.count + 3) / 4, kStripedMaxBlocks);
+            const uint32_t stride = bin.max_hap_len + 1;
+            const size_t need = (size_t)blocks * 4 * 3 * stride;
+            if (rb->carry32.n < need) HIP_TRY(rb->carry32.alloc(need));
+            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, a, rb->carry32.p, stride, blocks, c->stream));
+        }
     }
     return PHMM_OK;
 }
@@ -385,12 +410,12 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     HIP_TRY(hipStreamSynchronize(st));
     rb->last_rescued = n;
     if (n == 0) return PHMM_OK;
+    // the fp64 re-run: the striped systolic kernel in double, over the queue, results to raw64[pair]
+    const uint32_t blocks = std::min<uint32_t>((n + 3) / 4, kStripedMaxBlocks);
     const uint32_t stride = rb->max_hap_len + 1;
-    if (rb->scratch_pairs < n) {
-        HIP_TRY(rb->scratch.alloc((size_t)n * 3 * stride));
-        rb->scratch_pairs = n;
-    }
-    phmm::RescueArgs a{};
+    const size_t need = (size_t)blocks * 4 * 3 * stride;
+    if (rb->carry64.n < need) HIP_TRY(rb->carry64.alloc(need));
+    phmm::KernelArgs a{};
     a.read_bases = rb->read_bases.p;
     a.read_qual = rb->read_qual.p;
     a.read_ins = rb->read_ins.p;
@@ -398,19 +423,18 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     a.read_gcp = rb->read_gcp.p;
     a.read_off = rb->read_off.p;
     a.read_len = rb->read_len.p;
-    a.hap_bases = rb->hap_bases.p;
-    a.hap_off = rb->hap_off.p;
     a.hap_len = rb->hap_len.p;
+    a.planes = rb->planes.p;
+    a.plane_off = rb->plane_off.p;
     a.pair_read = rb->pair_read.p;
     a.pair_hap = rb->pair_hap.p;
-    a.rescue_list = rb->rescue_list.p;
-    a.n_rescue = rb->rescue_count.p;
+    a.order = rb->rescue_list.p;
+    a.n_pairs = n;
+    a.lds_words_per_group = phmm::striped_lds_words(rb->max_hap_len, 8);
     a.ph2pr = c->ph2pr_f64.p;
     a.mm_table = c->mm_f64.p;
-    a.scratch = rb->scratch.p;
-    a.scratch_stride = stride;
-    a.out_raw64 = rb->raw64.p;
-    HIP_TRY(phmm::launch_rescue_f64(a, n, st));
+    a.out_raw = rb->raw64.p;
+    HIP_TRY(phmm::launch_striped_f64(rb->uniform_gcp, a, rb->carry64.p, stride, blocks, st));
     return PHMM_OK;
 }
 

@@ -11,6 +11,9 @@ constexpr int kLanesPerPair = 16;     // one DPP row per (read, haplotype) pair;
 constexpr int kBlockThreads = 256;    // 4 waves = 16 pairs per workgroup
 constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take the single-pass kernel
 constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other
+constexpr int kStripedRowsF32 = 8;   // rows per lane of the striped fp32 kernel (stripes of 256 read rows)
+constexpr int kStripedRowsF64 = 4;    // rows per lane of the striped fp64 kernel (stripes of 128 read rows)
+constexpr int kStripedGroupsPerBlock = 4;  // the striped kernel runs one wave (4 pairs) per workgroup
 
 // 32-bit words per haplotype match plane (column j, 1-based, is bit 31-((j-1)&31) of word (j-1)>>5); one spare
 // word so that a window read [w, w+1] at the last sweep step (column H + 15) stays inside the plane
@@ -36,29 +39,22 @@ struct KernelArgs
     void *out_raw;  // [n_pairs of the whole batch], indexed by pair id
 };
 
-struct RescueArgs
-{
-    const uint8_t *read_bases, *read_qual, *read_ins, *read_del, *read_gcp;
-    const uint32_t *read_off, *read_len;
-    const uint8_t *hap_bases;
-    const uint32_t *hap_off, *hap_len;
-    const uint32_t *pair_read, *pair_hap;
-    const uint32_t *rescue_list;
-    const uint32_t *n_rescue;
-    const double *ph2pr;
-    const double *mm_table;
-    double *scratch;        // 3 * scratch_stride doubles per rescued pair
-    uint32_t scratch_stride;
-    double *out_raw64;      // indexed by pair id
-};
-
 hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const KernelArgs &a, hipStream_t s);
+// striped kernels: lds_words_per_group must include 3 * 32 carry values (see striped_lds_words); carry holds
+// 3 * carry_stride values per resident group (blocks * 4 groups)
+hipError_t launch_striped_f32(bool uniform_gcp, const KernelArgs &a, float *carry, uint32_t carry_stride, uint32_t blocks,
+                              hipStream_t s);
+hipError_t launch_striped_f64(bool uniform_gcp, const KernelArgs &a, double *carry, uint32_t carry_stride, uint32_t blocks,
+                              hipStream_t s);
+inline uint32_t striped_lds_words(uint32_t max_hap_len, uint32_t value_bytes)
+{
+    return kPlanes * planes_words(max_hap_len) + 3u * 32u * (value_bytes / 4u) + 2u;  // +2: keep the carry park 8-byte aligned
+}
 hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
                              const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,
                              hipStream_t s);
 hipError_t launch_collect_rescue(const float *raw, uint32_t n_pairs, uint32_t *list, uint32_t *count, uint32_t capacity,
                                  hipStream_t s);
-hipError_t launch_rescue_f64(const RescueArgs &a, uint32_t max_rescue, hipStream_t s);
 
 }  // namespace phmm
 #endif

@@ -319,70 +319,236 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_
 }
 
 // ----------------------------------------------------------------------------------------------------
-// fp64 rescue, first version: one pair per thread, row-major, previous row in a global scratch slab.
-// Same operation order as the fp32 kernels (and as oracle/phmm_oracle.c: phmm_oracle_pair_f64), scale 2^1020.
-// Only pairs whose fp32 sum fell below 1e-28f come here (pairhmm_internal.cpp:578-581).
+// the striped systolic kernel: reads longer than 16 * K rows, and every fp64 re-run.
+//
+// The read is cut into stripes of S = 16 * K rows, right-aligned (the boundary replicas sit on top of stripe 0, the
+// last read row is slot K-1 of lane 15 of the last stripe).  Each stripe is one full sweep of H + 15 steps exactly like
+// the single-pass kernel; what changes is the row above lane 0: in stripe 0 it is the boundary row, in later stripes it
+// is the last row of the previous stripe, which lane 15 wrote column by column into a per-group carry row in global
+// memory (3 * (H + 1) values, L2 / Infinity-Cache resident) -- the analogue of the reference's shift_out_m/x/y arrays
+// (core/avx512_s.cpp:277, :331-333).  The carry is read back 32 columns at a time (coalesced, one block ahead, agent-
+// scope loads so that no stale L1 line is served), parked in LDS, and lane 0 picks its column up as the `old` operand
+// of the DPP shift, so the inner loop gains three ds_read_b32 and no VALU work.  The carry is updated in place: the
+// write position (column t - 15) always trails the read-ahead position.
+// One wave per workgroup (4 pairs), grid-stride over the pair list: long-read batches are small and LDS-heavy.
 // ----------------------------------------------------------------------------------------------------
-__global__ void pairhmm_rescue_f64_kernel(RescueArgs a)
+template <typename T, int K, bool UG>
+__global__ void __launch_bounds__(64, 2) pairhmm_striped_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= *a.n_rescue) return;
-    const uint32_t pair = a.rescue_list[g];
-    const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
-    const uint32_t R = a.read_len[r], H = a.hap_len[h];
-    const uint32_t roff = a.read_off[r];
-    const uint8_t *hb = a.hap_bases + a.hap_off[h];
-    double *Mp = a.scratch + static_cast<size_t>(g) * 3 * a.scratch_stride;
-    double *Xp = Mp + a.scratch_stride, *Yp = Xp + a.scratch_stride;
-    const double init_y = __builtin_ldexp(1.0, 1020) / static_cast<double>(H);
-    for (uint32_t j = 0; j <= H; ++j) {
-        Mp[j] = 0.0;
-        Xp[j] = 0.0;
-        Yp[j] = init_y;
-    }
-    for (uint32_t i = 0; i < R; ++i) {
-        const uint32_t at = roff + i;
-        const uint32_t _i = a.read_ins[at] & 127u, _d = a.read_del[at] & 127u, _c = a.read_gcp[at] & 127u,
-                       _q = a.read_qual[at] & 127u;
-        const uint32_t mx = _i > _d ? _i : _d, mn = _i > _d ? _d : _i;
-        const double p_mm = a.mm_table[((mx * (mx + 1)) >> 1) + mn];
-        const double p_gapm = 1.0 - a.ph2pr[_c], p_mx = a.ph2pr[_i], p_xx = a.ph2pr[_c], p_my = a.ph2pr[_d],
-                     p_yy = a.ph2pr[_c];
-        const double dist = a.ph2pr[_q];
-        const double hi = 1.0 - dist, lo = __ddiv_rn(dist, 3.0);
-        const uint8_t rc = a.read_bases[at];
-        const uint32_t rcode = rc == 'A' ? 1u : rc == 'C' ? 2u : rc == 'T' ? 4u : rc == 'G' ? 8u : rc == 'N' ? 15u : 0u;
-        double Md = Mp[0], Xd = Xp[0], Yd = Yp[0], Ml = 0.0, Yl = 0.0;
-        Mp[0] = 0.0;
-        Xp[0] = 0.0;
-        Yp[0] = 0.0;
-        for (uint32_t j = 1; j <= H; ++j) {
-            const double Mu = Mp[j], Xu = Xp[j], Yu = Yp[j];
-            const uint8_t hc = hb[j - 1];
-            const uint32_t hcode = hc == 'A' ? 1u : hc == 'C' ? 2u : hc == 'T' ? 4u : hc == 'G' ? 8u : hc == 'N' ? 15u : 0u;
-            const double prior = (rcode & hcode) ? hi : lo;
-            double tt = Md * p_mm;
-            tt = __builtin_fma(Xd, p_gapm, tt);
-            tt = __builtin_fma(Yd, p_gapm, tt);
-            const double nM = tt * prior;
-            const double nX = __builtin_fma(Xu, p_xx, Mu * p_mx);
-            const double nY = __builtin_fma(Yl, p_yy, Ml * p_my);
-            Md = Mu;
-            Xd = Xu;
-            Yd = Yu;
-            Mp[j] = nM;
-            Xp[j] = nX;
-            Yp[j] = nY;
-            Ml = nM;
-            Yl = nY;
+    extern __shared__ uint32_t lds[];
+    constexpr int S = kLanesPerPair * K;
+    const uint32_t lane = threadIdx.x & 15u;
+    const uint32_t grp = threadIdx.x >> 4;  // 0..3
+    const uint32_t n_slots = gridDim.x * 4u;
+    const uint32_t slot = blockIdx.x * 4u + grp;
+    const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
+    const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
+    uint32_t *pl = lds + grp * a.lds_words_per_group;                 // planes, then 3 x 32 carry values
+    T *cbuf = reinterpret_cast<T *>(pl + a.lds_words_per_group - 3 * 32 * (sizeof(T) / 4));
+    T *cM = carry + static_cast<size_t>(slot) * 3 * carry_stride, *cX = cM + carry_stride, *cY = cX + carry_stride;
+
+    const uint32_t iters = (a.n_pairs + n_slots - 1) / n_slots;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t gidx = it * n_slots + slot;
+        const bool valid = gidx < a.n_pairs;
+        const uint32_t pair = a.order[valid ? gidx : 0];
+        const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
+        const uint32_t R = a.read_len[r], H = a.hap_len[h];
+        const uint32_t roff = a.read_off[r];
+        const uint32_t W = planes_words(H);
+        {
+            const uint32_t *src = a.planes + a.plane_off[h];
+            for (uint32_t i = lane; i < kPlanes * W; i += kLanesPerPair) pl[i] = src[i];
         }
+        const T init_y = Num<T>::init_const() / static_cast<T>(H);
+        const uint32_t n_stripes = valid ? (R + S - 1) / S : 0;
+        const int pad = static_cast<int>(n_stripes) * S - static_cast<int>(R);
+        uint32_t max_stripes = n_stripes;  // wave-uniform; a pair with fewer stripes joins late so that all end together
+        max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 16));
+        max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 32));
+        max_stripes = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_stripes);
+        const uint32_t wmax = W - 2;
+        T sumM = 0, sumX = 0;
+
+        for (uint32_t ws = 0; ws < max_stripes; ++ws) {
+            const bool in_play = ws + n_stripes >= max_stripes;
+            const uint32_t stripe = in_play ? ws + n_stripes - max_stripes : 0;  // this pair's stripe index
+            const bool first = stripe == 0, last = stripe + 1 == n_stripes;
+            // ---- per-row constants of this stripe ----
+            Rows<T, K, UG> P;
+            T M[K], X[K], Y[K];
+            uint32_t cls_lo = 0, cls_hi = 0;
+            if (UG) {
+                uint32_t c0 = a.read_gcp[roff] & 127u;
+                P.p_gapm_r[0] = static_cast<T>(1.0) - ph2pr[c0];
+                P.p_xx_r[0] = ph2pr[c0];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int row = static_cast<int>(stripe) * S + static_cast<int>(lane) * K + k - pad;
+                uint32_t cls = 5;
+                if (row >= 0) {
+                    const uint32_t at = roff + static_cast<uint32_t>(row);
+                    const uint32_t _i = a.read_ins[at] & 127u, _d = a.read_del[at] & 127u, _c = a.read_gcp[at] & 127u,
+                                   _q = a.read_qual[at] & 127u;
+                    const uint32_t mx = _i > _d ? _i : _d, mn = _i > _d ? _d : _i;
+                    P.p_mm[k] = mmtab[((mx * (mx + 1)) >> 1) + mn];
+                    P.p_mx[k] = ph2pr[_i];
+                    if (!UG) P.p_my_r[UG ? 0 : k] = ph2pr[_d];
+                    P.p_yy[k] = ph2pr[_c];
+                    if (!UG) {
+                        P.p_gapm_r[UG ? 0 : k] = static_cast<T>(1.0) - ph2pr[_c];
+                        P.p_xx_r[UG ? 0 : k] = ph2pr[_c];
+                    }
+                    const T dist = ph2pr[_q];
+                    P.hi[k] = static_cast<T>(1.0) - dist;
+                    P.lo[k] = Num<T>::div3(dist);
+                    cls = read_class(a.read_bases[at]);
+                    M[k] = 0;
+                    X[k] = 0;
+                    Y[k] = 0;
+                }
+                else {
+                    P.p_mm[k] = 0;
+                    P.p_mx[k] = 0;
+                    if (!UG) P.p_my_r[UG ? 0 : k] = 0;
+                    P.p_yy[k] = 1;
+                    if (!UG) {
+                        P.p_gapm_r[UG ? 0 : k] = 0;
+                        P.p_xx_r[UG ? 0 : k] = 0;
+                    }
+                    P.hi[k] = 0;
+                    P.lo[k] = 0;
+                    M[k] = 0;
+                    X[k] = 0;
+                    Y[k] = init_y;
+                }
+                if (k < 10)
+                    cls_lo |= cls << (3 * k);
+                else
+                    cls_hi |= cls << (3 * (k - 10));
+            }
+
+            const uint32_t Tg = (valid && in_play) ? H + (kLanesPerPair - 1) : 0;
+            uint32_t Tmax = Tg, Tmin = Tg;
+            Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+            Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+            Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
+            Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+            Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
+            Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
+
+            uint32_t mask[K];
+            // column 0 of the row above slot 0: init for the boundary row and its replicas (stripe 0 only), else 0
+            const T y_col0 = (first && static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
+            T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
+
+            // ---- carry-in: 32 columns per block, one block of read-ahead in registers ----
+            T preM[2], preX[2], preY[2];
+            auto carry_load = [&](uint32_t blk) {  // columns 32*blk + 1 + lane (+16)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    uint32_t j = 32u * blk + 1u + lane + 16u * q;
+                    j = j <= H ? j : H;
+                    if (first) {
+                        preM[q] = 0;
+                        preX[q] = 0;
+                        preY[q] = init_y;
+                    }
+                    else {
+                        preM[q] = __hip_atomic_load(cM + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        preX[q] = __hip_atomic_load(cX + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        preY[q] = __hip_atomic_load(cY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            };
+            auto carry_park = [&]() {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    cbuf[lane + 16 * q] = preM[q];
+                    cbuf[32 + lane + 16 * q] = preX[q];
+                    cbuf[64 + lane + 16 * q] = preY[q];
+                }
+            };
+            auto reload = [&](uint32_t t) {
+                const uint32_t jn = t > lane ? t - lane : 1u;
+                uint32_t w = (jn - 1) >> 5;
+                const uint32_t sh = (jn - 1) & 31u;
+                w = w < wmax ? w : wmax;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
+                    const uint32_t *p = pl + cls * W + w;
+                    const uint32_t w0 = p[0], w1 = p[1];
+                    mask[k] = (w0 << sh) | ((w1 >> 1) >> (31u - sh));
+                }
+                carry_park();                 // block (t-1)/32 becomes current
+                carry_load((t - 1) / 32 + 1);  // read ahead
+            };
+            auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
+                const uint32_t e = (t - 1) & 31u;
+                // lane 0 keeps `old` = the row above at column t (boundary row or carry); lanes 1..15 take lane-1's last row
+                uM0 = dpp_row_shr1(cbuf[e], M[K - 1]);
+                uX0 = dpp_row_shr1(cbuf[32 + e], X[K - 1]);
+                uY0 = dpp_row_shr1(cbuf[64 + e], Y[K - 1]);
+#pragma unroll
+                for (int k = K - 1; k >= 0; --k) {
+                    uint32_t nm;
+                    const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
+                    mask[k] = nm;
+                    const T prior = hit ? P.hi[k] : P.lo[k];
+                    Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my(k));
+                    const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
+                    T tt = gM * P.p_mm[k];
+                    tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
+                    tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
+                    M[k] = tt * prior;
+                }
+                T uM = uM0, uX = uX0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    X[k] = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
+                    uM = M[k];
+                    uX = X[k];
+                }
+                if (last) {
+                    sumM = sumM + M[K - 1];
+                    sumX = sumX + X[K - 1];
+                }
+                else if (lane == kLanesPerPair - 1) {
+                    const uint32_t j = t - (kLanesPerPair - 1);  // lane 15 is at column t - 15 >= 1 whenever it is active
+                    cM[j] = M[K - 1];
+                    cX[j] = X[K - 1];
+                    cY[j] = Y[K - 1];
+                }
+            };
+            auto step_t = [&](uint32_t t) {
+                if (t & 1u)
+                    step(t, aM, aX, aY, bM, bX, bY);
+                else
+                    step(t, bM, bX, bY, aM, aX, aY);
+            };
+
+            carry_load(0);
+            uint32_t t = 1;
+            const uint32_t Tfill = Tmax < (uint32_t)(kLanesPerPair - 1) ? Tmax : (uint32_t)(kLanesPerPair - 1);
+            for (; t <= Tfill; ++t) {
+                if ((t & 31u) == 1u) reload(t);
+                if ((t > lane) && (t <= Tg)) step_t(t);
+            }
+            for (; t <= Tmin; ++t) {
+                if ((t & 31u) == 1u) reload(t);
+                step_t(t);
+            }
+            for (; t <= Tmax; ++t) {
+                if ((t & 31u) == 1u) reload(t);
+                if (t <= Tg) step_t(t);
+            }
+            // the next stripe of this wave reads what lane 15 just wrote: drain the stores first
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        if (valid && lane == kLanesPerPair - 1) reinterpret_cast<T *>(a.out_raw)[pair] = sumM + sumX;
     }
-    double sum_m = 0.0, sum_x = 0.0;
-    for (uint32_t j = 1; j <= H; ++j) {
-        sum_m = sum_m + Mp[j];
-        sum_x = sum_x + Xp[j];
-    }
-    a.out_raw64[pair] = sum_m + sum_x;
 }
 
 // fp32 results below the acceptance threshold (rovaca/common.h:9, MIN_ACCEPTED 1e-28f) are queued for fp64
@@ -426,6 +592,34 @@ hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const Kernel
     return uniform_gcp ? launch_k<float, true, 1>(rows_per_lane, a, s) : launch_k<float, false, 1>(rows_per_lane, a, s);
 }
 
+template <typename T, int K>
+static hipError_t launch_striped_t(bool uniform_gcp, const KernelArgs &a, void *carry, uint32_t carry_stride, uint32_t blocks,
+                                   hipStream_t s)
+{
+    const size_t shmem = 4u * a.lds_words_per_group * sizeof(uint32_t);
+    if (uniform_gcp)
+        hipLaunchKernelGGL((pairhmm_striped_kernel<T, K, true>), dim3(blocks), dim3(64), shmem, s, a, static_cast<T *>(carry),
+                           carry_stride);
+    else
+        hipLaunchKernelGGL((pairhmm_striped_kernel<T, K, false>), dim3(blocks), dim3(64), shmem, s, a, static_cast<T *>(carry),
+                           carry_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_striped_f32(bool uniform_gcp, const KernelArgs &a, float *carry, uint32_t carry_stride, uint32_t blocks,
+                              hipStream_t s)
+{
+    if (a.n_pairs == 0) return hipSuccess;
+    return launch_striped_t<float, kStripedRowsF32>(uniform_gcp, a, carry, carry_stride, blocks, s);
+}
+
+hipError_t launch_striped_f64(bool uniform_gcp, const KernelArgs &a, double *carry, uint32_t carry_stride, uint32_t blocks,
+                              hipStream_t s)
+{
+    if (a.n_pairs == 0) return hipSuccess;
+    return launch_striped_t<double, kStripedRowsF64>(uniform_gcp, a, carry, carry_stride, blocks, s);
+}
+
 hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
                              const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,
                              hipStream_t s)
@@ -442,13 +636,6 @@ hipError_t launch_collect_rescue(const float *raw, uint32_t n_pairs, uint32_t *l
     if (n_pairs == 0) return hipSuccess;
     hipLaunchKernelGGL(collect_rescue_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, raw, n_pairs, list, count,
                        capacity);
-    return hipGetLastError();
-}
-
-hipError_t launch_rescue_f64(const RescueArgs &a, uint32_t max_rescue, hipStream_t s)
-{
-    if (max_rescue == 0) return hipSuccess;
-    hipLaunchKernelGGL(pairhmm_rescue_f64_kernel, dim3((max_rescue + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

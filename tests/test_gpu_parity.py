@@ -161,3 +161,36 @@ def test_full_size_properties_config2(engine):
     oraw, ol10, _ = oracle.batch(b.subset(idx), n_threads=16)
     assert np.array_equal(raw[idx].view(np.uint32), oraw.view(np.uint32))
     assert np.array_equal(l10[idx], ol10)
+
+
+def test_long_reads_striped_kernel(engine):
+    # reads above 256 bases take the striped kernel (stripes of 128 rows chained through a carry row in global memory)
+    rng = np.random.default_rng(8)
+    reads, haps, pairs = [], [], []
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for R, H in [(257, 300), (258, 257), (300, 700), (383, 384), (384, 385), (385, 1000), (512, 512), (640, 129),
+                 (1000, 1500), (1537, 2000), (2000, 2100), (129, 5000), (40, 4097)]:
+        hap = acgt[rng.integers(0, 4, H)]
+        st = int(rng.integers(0, max(1, H - R + 1)))
+        seq = np.resize(hap[st:st + R], R).copy()
+        seq[rng.random(R) < 0.02] = ord("G")
+        q = rng.choice(np.array([6, 25, 37], np.uint8), R, p=[0.05, 0.15, 0.8])
+        g = np.full(R, 40, np.uint8)
+        reads.append((seq, q, g, g, np.full(R, 10, np.uint8)))
+        haps.append(hap)
+        pairs.append((len(reads) - 1, len(haps) - 1))
+    pairs += [(0, 3), (5, 2), (9, 9), (3, 8)]  # mixed stripe counts inside one wave
+    _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
+
+
+def test_config5_sample_long_reads(engine):
+    # BASELINE config 5 shape at reduced count: reads 2-10 kbp x haps up to 12 kbp.  The scalar oracle needs ~1 s per
+    # 1e8 cells, so the sample is 6 pairs; fixed pre-scaling underflows fp32 on such reads -> most pairs are rescued.
+    b = synth.make_batch(seed=5, n_regions=2, reads=3, haps=1, read_len=(2000, 6000), hap_len=(6000, 9000))
+    raw, l10, st = engine.compute(b)
+    oraw, ol10, oresc = oracle.batch(b, n_threads=6)
+    assert np.array_equal(raw.view(np.uint32), oraw.view(np.uint32))
+    fin = np.isfinite(ol10)
+    assert np.array_equal(l10[fin], ol10[fin])  # fp32-accepted identical, fp64-rescued identical (same op order)
+    assert np.array_equal(np.isfinite(l10), fin)
+    assert int(st.n_rescued) == int(oresc.sum())
