@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--scale", type=float, default=1.0, help="multiplies the number of regions of the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

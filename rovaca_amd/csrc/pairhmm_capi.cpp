@@ -83,18 +83,31 @@ struct Bin
     int rows_per_lane;      // 1..16: single-pass kernel <K>; 0: striped kernel (long read or long haplotype)
     uint32_t first, count;  // range of `order`
     uint32_t lds_words_per_group;
-    uint32_t max_hap_len;
+    uint32_t max_hap_len, max_read_len;
 };
+
+// How many waves cooperate on one quad of pairs in the striped kernel: enough stripes to keep them busy, a haplotype long
+// enough for the pipeline lag (kLag = 4 supersteps of 32 columns per wave), and only when the batch is too small to fill the
+// chip with one wave per quad.
+static int pick_waves_per_team(uint32_t n_pairs, uint32_t max_read, uint32_t max_hap, uint32_t stripe_rows)
+{
+    const uint32_t quads = (n_pairs + 3) / 4;
+    const uint32_t stripes = (max_read + stripe_rows - 1) / stripe_rows;
+    const uint32_t supersteps = (max_hap + 15 + 31) / 32;
+    if (quads < 2048 && stripes >= 8 && supersteps >= 4 * 8 + 12) return 8;
+    if (quads < 4096 && stripes >= 4 && supersteps >= 4 * 4 + 12) return 4;
+    return 1;
+}
 
 // single-pass kernels keep 16 pairs' haplotype planes in LDS per workgroup; longer haplotypes take the striped kernel
 constexpr uint32_t kSinglePassMaxHap = 4096;
 constexpr uint32_t kMaxLen = 1u << 20;
-constexpr uint32_t kStripedMaxBlocks = 1024;  // resident groups that own a carry row: 4 per block
+constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
 
 struct phmm_resident
 {
     uint64_t n_pairs = 0, cells = 0;
-    uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0;
+    uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
     bool uniform_gcp = false;
     DevBuf<uint8_t> read_bases, read_qual, read_ins, read_del, read_gcp, hap_bases;
     DevBuf<uint32_t> read_off, read_len, hap_off, hap_len, pair_read, pair_hap, order;
@@ -229,7 +242,7 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
     }
     if (max_read > kMaxLen || max_hap > kMaxLen)
         return fail(PHMM_E_INVALID, "phmm_upload: sequence longer than %u bases", kMaxLen);
-    if ((uint64_t)phmm::kStripedGroupsPerBlock * phmm::striped_lds_words(max_hap, 8) * sizeof(uint32_t) > 64u * 1024u)
+    if (phmm::team_lds_bytes((uint32_t)phmm::kPlanes * phmm::planes_words(max_hap), 8, 8) > 160u * 1024u)
         return fail(PHMM_E_INVALID, "phmm_upload: haplotype of %u bases exceeds the LDS plane budget", max_hap);
 
     phmm_resident *rb = new (std::nothrow) phmm_resident();
@@ -243,6 +256,7 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
     rb->n_reads = b->n_reads;
     rb->n_haps = b->n_haps;
     rb->max_hap_len = max_hap;
+    rb->max_read_len = max_read;
 
     // ---- pair list (materialise the cross product), length binning ----
     std::vector<uint32_t> pr(n_pairs), ph(n_pairs);
@@ -284,15 +298,14 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
     for (uint64_t i = 0; i < n_pairs;) {
         const int cls = (int)(keys[i] >> 58);
         uint64_t j = i;
-        uint32_t hmax = 0;
+        uint32_t hmax = 0, rmax = 0;
         while (j < n_pairs && (int)(keys[j] >> 58) == cls) {
             hmax = std::max(hmax, b->hap_len[ph[order[j]]]);
+            rmax = std::max(rmax, b->read_len[pr[order[j]]]);
             ++j;
         }
-        if (cls == 17)
-            rb->bins.push_back(Bin{0, (uint32_t)i, (uint32_t)(j - i), phmm::striped_lds_words(hmax, 4), hmax});
-        else
-            rb->bins.push_back(Bin{cls, (uint32_t)i, (uint32_t)(j - i), (uint32_t)phmm::kPlanes * phmm::planes_words(hmax), hmax});
+        const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
+        rb->bins.push_back(Bin{cls == 17 ? 0 : cls, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax});
         i = j;
     }
     rb->cells = cells;
@@ -388,11 +401,13 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
             HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, c->stream));
         }
         else {
-            const uint32_t blocks = std::min<uint32_t>((bin.count + 3) / 4, kStripedMaxBlocks);
+            const int wp = pick_waves_per_team(bin.count, bin.max_read_len, bin.max_hap_len,
+                                               phmm::kLanesPerPair * phmm::kStripedRowsF32);
+            const uint32_t teams = std::min<uint32_t>((bin.count + 3) / 4, kStripedMaxTeams / wp);
             const uint32_t stride = bin.max_hap_len + 1;
-            const size_t need = (size_t)blocks * 4 * 3 * stride;
+            const size_t need = phmm::team_carry_values(teams, wp, stride);
             if (rb->carry32.n < need) HIP_TRY(rb->carry32.alloc(need));
-            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, a, rb->carry32.p, stride, blocks, c->stream));
+            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, wp, a, rb->carry32.p, stride, teams, c->stream));
         }
     }
     return PHMM_OK;
@@ -411,9 +426,10 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     rb->last_rescued = n;
     if (n == 0) return PHMM_OK;
     // the fp64 re-run: the striped systolic kernel in double, over the queue, results to raw64[pair]
-    const uint32_t blocks = std::min<uint32_t>((n + 3) / 4, kStripedMaxBlocks);
+    const int wp = pick_waves_per_team(n, rb->max_read_len, rb->max_hap_len, phmm::kLanesPerPair * phmm::kStripedRowsF64);
+    const uint32_t teams = std::min<uint32_t>((n + 3) / 4, kStripedMaxTeams / wp);
     const uint32_t stride = rb->max_hap_len + 1;
-    const size_t need = (size_t)blocks * 4 * 3 * stride;
+    const size_t need = phmm::team_carry_values(teams, wp, stride);
     if (rb->carry64.n < need) HIP_TRY(rb->carry64.alloc(need));
     phmm::KernelArgs a{};
     a.read_bases = rb->read_bases.p;
@@ -430,11 +446,11 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     a.pair_hap = rb->pair_hap.p;
     a.order = rb->rescue_list.p;
     a.n_pairs = n;
-    a.lds_words_per_group = phmm::striped_lds_words(rb->max_hap_len, 8);
+    a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(rb->max_hap_len);
     a.ph2pr = c->ph2pr_f64.p;
     a.mm_table = c->mm_f64.p;
     a.out_raw = rb->raw64.p;
-    HIP_TRY(phmm::launch_striped_f64(rb->uniform_gcp, a, rb->carry64.p, stride, blocks, st));
+    HIP_TRY(phmm::launch_striped_f64(rb->uniform_gcp, wp, a, rb->carry64.p, stride, teams, st));
     return PHMM_OK;
 }
 

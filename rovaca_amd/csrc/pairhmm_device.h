@@ -13,7 +13,7 @@ constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take 
 constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other
 constexpr int kStripedRowsF32 = 8;   // rows per lane of the striped fp32 kernel (stripes of 256 read rows)
 constexpr int kStripedRowsF64 = 4;    // rows per lane of the striped fp64 kernel (stripes of 128 read rows)
-constexpr int kStripedGroupsPerBlock = 4;  // the striped kernel runs one wave (4 pairs) per workgroup
+constexpr int kStripedGroupsPerBlock = 4;  // a team (1, 4 or 8 waves) of the striped kernel sweeps four pairs
 
 // 32-bit words per haplotype match plane (column j, 1-based, is bit 31-((j-1)&31) of word (j-1)>>5); one spare
 // word so that a window read [w, w+1] at the last sweep step (column H + 15) stays inside the plane
@@ -40,15 +40,19 @@ struct KernelArgs
 };
 
 hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const KernelArgs &a, hipStream_t s);
-// striped kernels: lds_words_per_group must include 3 * 32 carry values (see striped_lds_words); carry holds
-// 3 * carry_stride values per resident group (blocks * 4 groups)
-hipError_t launch_striped_f32(bool uniform_gcp, const KernelArgs &a, float *carry, uint32_t carry_stride, uint32_t blocks,
-                              hipStream_t s);
-hipError_t launch_striped_f64(bool uniform_gcp, const KernelArgs &a, double *carry, uint32_t carry_stride, uint32_t blocks,
-                              hipStream_t s);
-inline uint32_t striped_lds_words(uint32_t max_hap_len, uint32_t value_bytes)
+// striped ("team") kernels: a workgroup of waves_per_team waves (1, 4 or 8) sweeps four pairs; lds_words_per_group is
+// kPlanes * planes_words(longest haplotype of the launch); carry holds 3 * carry_stride values per (team, wave, group).
+hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, const KernelArgs &a, float *carry, uint32_t carry_stride,
+                              uint32_t teams, hipStream_t s);
+hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, const KernelArgs &a, double *carry, uint32_t carry_stride,
+                              uint32_t teams, hipStream_t s);
+inline size_t team_lds_bytes(uint32_t plane_words_per_group, int waves_per_team, size_t value_bytes)
 {
-    return kPlanes * planes_words(max_hap_len) + 3u * 32u * (value_bytes / 4u) + 2u;  // +2: keep the carry park 8-byte aligned
+    return 4u * (size_t)plane_words_per_group * sizeof(uint32_t) + (size_t)waves_per_team * 4u * 3u * 64u * value_bytes;
+}
+inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t carry_stride)
+{
+    return (size_t)teams * waves_per_team * 4u * 3u * carry_stride;
 }
 hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
                              const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,

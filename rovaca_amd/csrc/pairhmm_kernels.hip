@@ -319,65 +319,173 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_
 }
 
 // ----------------------------------------------------------------------------------------------------
-// the striped systolic kernel: reads longer than 16 * K rows, and every fp64 re-run.
+// the striped ("team") systolic kernel: reads longer than 16 * K rows, very long haplotypes, and every fp64 re-run.
 //
-// The read is cut into stripes of S = 16 * K rows, right-aligned (the boundary replicas sit on top of stripe 0, the
-// last read row is slot K-1 of lane 15 of the last stripe).  Each stripe is one full sweep of H + 15 steps exactly like
-// the single-pass kernel; what changes is the row above lane 0: in stripe 0 it is the boundary row, in later stripes it
-// is the last row of the previous stripe, which lane 15 wrote column by column into a per-group carry row in global
-// memory (3 * (H + 1) values, L2 / Infinity-Cache resident) -- the analogue of the reference's shift_out_m/x/y arrays
-// (core/avx512_s.cpp:277, :331-333).  The carry is read back 32 columns at a time (coalesced, one block ahead, agent-
-// scope loads so that no stale L1 line is served), parked in LDS, and lane 0 picks its column up as the `old` operand
-// of the DPP shift, so the inner loop gains three ds_read_b32 and no VALU work.  The carry is updated in place: the
-// write position (column t - 15) always trails the read-ahead position.
-// One wave per workgroup (4 pairs), grid-stride over the pair list: long-read batches are small and LDS-heavy.
+// The read is cut into stripes of S = 16 * K rows, right-aligned (the boundary replicas sit on top of stripe 0, the last
+// read row is slot K-1 of lane 15 of the last stripe).  A stripe is one sweep of H + 15 steps exactly like the single-pass
+// kernel; what changes is the row above lane 0: in stripe 0 it is the boundary row, in later stripes the last row of the
+// previous stripe, which lane 15 wrote column by column into a carry row in global memory (3 * (H + 1) values, L2 /
+// Infinity-Cache resident) -- the analogue of the reference's shift_out_m/x/y arrays (core/avx512_s.cpp:277, :331-333).
+// The carry is read back 32 columns at a time (coalesced, two blocks ahead, agent-scope loads so no stale L1 line is
+// served), parked in an LDS ring, and lane 0 picks its column up as the `old` operand of the DPP shift.
+//
+// Multi-wavefront per pair: a workgroup is a TEAM of WP waves that works on the same four pairs.  Wave w owns the stripes
+// v = w, w + WP, w + 2 WP, ... and runs kLag supersteps (of 32 steps) behind wave w-1, so the stripes of one pair are swept
+// as a software pipeline along the haplotype; one __syncthreads() per superstep orders carry writes before the reads
+// that need them.  WP = 1 is the plain striped sweep (no pipeline, the barrier is trivial).  This is what fills the chip
+// when a batch has few, long pairs (BASELINE config 5), and it is how the fp64 re-run is done.
 // ----------------------------------------------------------------------------------------------------
-template <typename T, int K, bool UG>
-__global__ void __launch_bounds__(64, 2) pairhmm_striped_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
+constexpr uint32_t kLag = 4;  // supersteps between consecutive stripes of a pair: the consumer reads two blocks ahead
+
+template <typename T, int K, bool UG, int WP>
+__global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
 {
     extern __shared__ uint32_t lds[];
     constexpr int S = kLanesPerPair * K;
+    constexpr uint32_t kRing = 64;  // columns parked per value: two blocks of 32
     const uint32_t lane = threadIdx.x & 15u;
-    const uint32_t grp = threadIdx.x >> 4;  // 0..3
-    const uint32_t n_slots = gridDim.x * 4u;
-    const uint32_t slot = blockIdx.x * 4u + grp;
+    const uint32_t grp = (threadIdx.x >> 4) & 3u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t team = blockIdx.x, n_teams = gridDim.x;
     const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
     const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
-    uint32_t *pl = lds + grp * a.lds_words_per_group;                 // planes, then 3 x 32 carry values
-    T *cbuf = reinterpret_cast<T *>(pl + a.lds_words_per_group - 3 * 32 * (sizeof(T) / 4));
-    T *cM = carry + static_cast<size_t>(slot) * 3 * carry_stride, *cX = cM + carry_stride, *cY = cX + carry_stride;
+    // LDS: [4 groups][planes] shared by the team, then [WP waves][4 groups][3 values][kRing] carry ring
+    const uint32_t plane_words = a.lds_words_per_group;
+    uint32_t *pl = lds + grp * plane_words;
+    T *ring = reinterpret_cast<T *>(lds + 4u * plane_words) + (static_cast<size_t>(wave) * 4u + grp) * 3u * kRing;
+    // carry rows: one per (team, wave, group); stripe v reads the row of the wave that ran stripe v - 1
+    const uint32_t prev_wave = (wave + WP - 1) % WP;
+    T *wM = carry + ((static_cast<size_t>(team) * WP + wave) * 4u + grp) * 3u * carry_stride;
+    T *wX = wM + carry_stride, *wY = wX + carry_stride;
+    const T *rM = carry + ((static_cast<size_t>(team) * WP + prev_wave) * 4u + grp) * 3u * carry_stride;
+    const T *rX = rM + carry_stride, *rY = rX + carry_stride;
 
-    const uint32_t iters = (a.n_pairs + n_slots - 1) / n_slots;
+    const uint32_t quads = (a.n_pairs + 3u) / 4u;
+    const uint32_t iters = (quads + n_teams - 1) / n_teams;
     for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t gidx = it * n_slots + slot;
+        const uint32_t gidx = (it * n_teams + team) * 4u + grp;
         const bool valid = gidx < a.n_pairs;
         const uint32_t pair = a.order[valid ? gidx : 0];
         const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
         const uint32_t R = a.read_len[r], H = a.hap_len[h];
         const uint32_t roff = a.read_off[r];
         const uint32_t W = planes_words(H);
+        __syncthreads();  // the previous quad's planes are no longer read
         {
             const uint32_t *src = a.planes + a.plane_off[h];
-            for (uint32_t i = lane; i < kPlanes * W; i += kLanesPerPair) pl[i] = src[i];
+            for (uint32_t i = lane + kLanesPerPair * wave; i < kPlanes * W; i += kLanesPerPair * WP) pl[i] = src[i];
         }
         const T init_y = Num<T>::init_const() / static_cast<T>(H);
         const uint32_t n_stripes = valid ? (R + S - 1) / S : 0;
         const int pad = static_cast<int>(n_stripes) * S - static_cast<int>(R);
-        uint32_t max_stripes = n_stripes;  // wave-uniform; a pair with fewer stripes joins late so that all end together
+        uint32_t max_stripes = n_stripes;  // team-uniform; a pair with fewer stripes joins late so that all end together
         max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 16));
         max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 32));
         max_stripes = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_stripes);
+        const uint32_t Tpair = valid ? H + (kLanesPerPair - 1) : 0;
+        uint32_t Tmax = Tpair;
+        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+        Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
+        const uint32_t Bs = (Tmax + 31u) / 32u;                // supersteps per stripe
+        const uint32_t n_rounds = (max_stripes + WP - 1) / WP;  // stripes per wave
+        const uint32_t G = n_rounds * Bs + kLag * (WP - 1);     // supersteps of this quad
         const uint32_t wmax = W - 2;
-        T sumM = 0, sumX = 0;
+        __syncthreads();  // planes staged
 
-        for (uint32_t ws = 0; ws < max_stripes; ++ws) {
-            const bool in_play = ws + n_stripes >= max_stripes;
-            const uint32_t stripe = in_play ? ws + n_stripes - max_stripes : 0;  // this pair's stripe index
-            const bool first = stripe == 0, last = stripe + 1 == n_stripes;
-            // ---- per-row constants of this stripe ----
-            Rows<T, K, UG> P;
-            T M[K], X[K], Y[K];
-            uint32_t cls_lo = 0, cls_hi = 0;
+        // per-stripe state (lives in registers across supersteps)
+        Rows<T, K, UG> P;
+        T M[K], X[K], Y[K];
+        uint32_t mask[K];
+        uint32_t cls_lo = 0, cls_hi = 0;
+        T aM = 0, aX = 0, aY = 0, bM = 0, bX = 0, bY = 0;
+        T preM[2], preX[2], preY[2];
+        T curM = 0, curX = 0, curY = 0;  // the row above lane 0 at the next step's column (prefetched from the ring)
+        T sumM = 0, sumX = 0;
+        uint32_t Tg = 0;
+        bool first = false, last = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            M[k] = 0;
+            X[k] = 0;
+            Y[k] = 0;
+            mask[k] = 0;
+            P.p_mm[k] = 0;
+            P.p_mx[k] = 0;
+            P.p_yy[k] = 0;
+            P.lo[k] = 0;
+            P.hi[k] = 0;
+            if (!UG) {
+                P.p_my_r[UG ? 0 : k] = 0;
+                P.p_gapm_r[UG ? 0 : k] = 0;
+                P.p_xx_r[UG ? 0 : k] = 0;
+            }
+        }
+        if (UG) {
+            P.p_gapm_r[0] = 0;
+            P.p_xx_r[0] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            preM[q] = 0;
+            preX[q] = 0;
+            preY[q] = 0;
+        }
+
+        auto carry_load = [&](uint32_t blk) {  // columns 32 * blk + 1 + lane (+ 16) of the producer's row
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint32_t j = 32u * blk + 1u + lane + 16u * q;
+                j = j <= H ? j : H;
+                if (first) {
+                    preM[q] = 0;
+                    preX[q] = 0;
+                    preY[q] = init_y;
+                }
+                else {
+                    preM[q] = __hip_atomic_load(rM + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    preX[q] = __hip_atomic_load(rX + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    preY[q] = __hip_atomic_load(rY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        auto carry_park = [&](uint32_t blk) {
+            const uint32_t base = (blk & 1u) * 32u + lane;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ring[base + 16 * q] = preM[q];
+                ring[kRing + base + 16 * q] = preX[q];
+                ring[2 * kRing + base + 16 * q] = preY[q];
+            }
+        };
+        auto ring_fetch = [&](uint32_t t) {  // column t
+            const uint32_t e = (t - 1) & (kRing - 1);
+            curM = ring[e];
+            curX = ring[kRing + e];
+            curY = ring[2 * kRing + e];
+        };
+        auto masks_reload = [&](uint32_t t) {
+            const uint32_t jn = t > lane ? t - lane : 1u;
+            uint32_t w = (jn - 1) >> 5;
+            const uint32_t sh = (jn - 1) & 31u;
+            w = w < wmax ? w : wmax;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
+                const uint32_t *p = pl + cls * W + w;
+                const uint32_t w0 = p[0], w1 = p[1];
+                mask[k] = (w0 << sh) | ((w1 >> 1) >> (31u - sh));
+            }
+        };
+        auto stripe_setup = [&](uint32_t v) {
+            const bool in_play = v + n_stripes >= max_stripes;
+            const uint32_t stripe = in_play ? v + n_stripes - max_stripes : 0;  // this pair's own stripe index
+            first = stripe == 0;
+            last = stripe + 1 == n_stripes;
+            const bool live = valid && in_play;
+            Tg = live ? Tpair : 0;
+            cls_lo = 0;
+            cls_hi = 0;
             if (UG) {
                 uint32_t c0 = a.read_gcp[roff] & 127u;
                 P.p_gapm_r[0] = static_cast<T>(1.0) - ph2pr[c0];
@@ -387,7 +495,7 @@ __global__ void __launch_bounds__(64, 2) pairhmm_striped_kernel(KernelArgs a, T 
             for (int k = 0; k < K; ++k) {
                 const int row = static_cast<int>(stripe) * S + static_cast<int>(lane) * K + k - pad;
                 uint32_t cls = 5;
-                if (row >= 0) {
+                if (live && row >= 0) {
                     const uint32_t at = roff + static_cast<uint32_t>(row);
                     const uint32_t _i = a.read_ins[at] & 127u, _d = a.read_del[at] & 127u, _c = a.read_gcp[at] & 127u,
                                    _q = a.read_qual[at] & 127u;
@@ -428,126 +536,94 @@ __global__ void __launch_bounds__(64, 2) pairhmm_striped_kernel(KernelArgs a, T 
                 else
                     cls_hi |= cls << (3 * (k - 10));
             }
-
-            const uint32_t Tg = (valid && in_play) ? H + (kLanesPerPair - 1) : 0;
-            uint32_t Tmax = Tg, Tmin = Tg;
-            Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
-            Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
-            Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
-            Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
-            Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
-            Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
-
-            uint32_t mask[K];
             // column 0 of the row above slot 0: init for the boundary row and its replicas (stripe 0 only), else 0
             const T y_col0 = (first && static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
-            T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
-
-            // ---- carry-in: 32 columns per block, one block of read-ahead in registers ----
-            T preM[2], preX[2], preY[2];
-            auto carry_load = [&](uint32_t blk) {  // columns 32*blk + 1 + lane (+16)
+            aM = 0;
+            aX = 0;
+            aY = y_col0;
+            bM = 0;
+            bX = 0;
+            bY = y_col0;
+            if (first) {
+                sumM = 0;
+                sumX = 0;
+            }
+            // carry ring: blocks 0 and 1 parked, block 2 in flight
+            carry_load(0);
+            carry_park(0);
+            carry_load(1);
+            carry_park(1);
+            carry_load(2);
+            ring_fetch(1);
+        };
+        auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
+            // lane 0 keeps `old` = the row above at column t (boundary row or carry); lanes 1..15 take lane-1's last row
+            uM0 = dpp_row_shr1(curM, M[K - 1]);
+            uX0 = dpp_row_shr1(curX, X[K - 1]);
+            uY0 = dpp_row_shr1(curY, Y[K - 1]);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    uint32_t j = 32u * blk + 1u + lane + 16u * q;
-                    j = j <= H ? j : H;
-                    if (first) {
-                        preM[q] = 0;
-                        preX[q] = 0;
-                        preY[q] = init_y;
+            for (int k = K - 1; k >= 0; --k) {
+                uint32_t nm;
+                const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
+                mask[k] = nm;
+                const T prior = hit ? P.hi[k] : P.lo[k];
+                Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my(k));
+                const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
+                T tt = gM * P.p_mm[k];
+                tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
+                tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
+                M[k] = tt * prior;
+            }
+            T uM = uM0, uX = uX0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                X[k] = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
+                uM = M[k];
+                uX = X[k];
+            }
+            if (last) {
+                sumM = sumM + M[K - 1];
+                sumX = sumX + X[K - 1];
+            }
+            else if (lane == kLanesPerPair - 1) {
+                const uint32_t j = t - (kLanesPerPair - 1);  // lane 15 is at column t - 15 >= 1 whenever it is active
+                wM[j] = M[K - 1];
+                wX[j] = X[K - 1];
+                wY[j] = Y[K - 1];
+            }
+        };
+
+        for (uint32_t g = 0; g < G; ++g) {
+            const int32_t tau = static_cast<int32_t>(g) - static_cast<int32_t>(kLag * wave);
+            if (tau >= 0 && static_cast<uint32_t>(tau) < n_rounds * Bs) {
+                const uint32_t round = static_cast<uint32_t>(tau) / Bs, c = static_cast<uint32_t>(tau) % Bs;
+                const uint32_t v = round * WP + wave;
+                if (v < max_stripes) {
+                    if (c == 0) {
+                        stripe_setup(v);
                     }
                     else {
-                        preM[q] = __hip_atomic_load(cM + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        preX[q] = __hip_atomic_load(cX + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        preY[q] = __hip_atomic_load(cY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        carry_park(c + 1);  // block c + 1 joins the ring (block c was parked one superstep ago)
+                        carry_load(c + 2);
                     }
+                    const uint32_t t0 = 32u * c + 1u;
+                    masks_reload(t0);
+                    const uint32_t t1 = min(t0 + 31u, Tmax);
+                    for (uint32_t t = t0; t <= t1; ++t) {
+                        if ((t > lane) && (t <= Tg)) {
+                            if (t & 1u)
+                                step(t, aM, aX, aY, bM, bX, bY);
+                            else
+                                step(t, bM, bX, bY, aM, aX, aY);
+                        }
+                        ring_fetch(t + 1);
+                    }
+                    if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == kLanesPerPair - 1)
+                        reinterpret_cast<T *>(a.out_raw)[pair] = sumM + sumX;
                 }
-            };
-            auto carry_park = [&]() {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    cbuf[lane + 16 * q] = preM[q];
-                    cbuf[32 + lane + 16 * q] = preX[q];
-                    cbuf[64 + lane + 16 * q] = preY[q];
-                }
-            };
-            auto reload = [&](uint32_t t) {
-                const uint32_t jn = t > lane ? t - lane : 1u;
-                uint32_t w = (jn - 1) >> 5;
-                const uint32_t sh = (jn - 1) & 31u;
-                w = w < wmax ? w : wmax;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
-                    const uint32_t *p = pl + cls * W + w;
-                    const uint32_t w0 = p[0], w1 = p[1];
-                    mask[k] = (w0 << sh) | ((w1 >> 1) >> (31u - sh));
-                }
-                carry_park();                 // block (t-1)/32 becomes current
-                carry_load((t - 1) / 32 + 1);  // read ahead
-            };
-            auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
-                const uint32_t e = (t - 1) & 31u;
-                // lane 0 keeps `old` = the row above at column t (boundary row or carry); lanes 1..15 take lane-1's last row
-                uM0 = dpp_row_shr1(cbuf[e], M[K - 1]);
-                uX0 = dpp_row_shr1(cbuf[32 + e], X[K - 1]);
-                uY0 = dpp_row_shr1(cbuf[64 + e], Y[K - 1]);
-#pragma unroll
-                for (int k = K - 1; k >= 0; --k) {
-                    uint32_t nm;
-                    const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
-                    mask[k] = nm;
-                    const T prior = hit ? P.hi[k] : P.lo[k];
-                    Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my(k));
-                    const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
-                    T tt = gM * P.p_mm[k];
-                    tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
-                    tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
-                    M[k] = tt * prior;
-                }
-                T uM = uM0, uX = uX0;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    X[k] = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
-                    uM = M[k];
-                    uX = X[k];
-                }
-                if (last) {
-                    sumM = sumM + M[K - 1];
-                    sumX = sumX + X[K - 1];
-                }
-                else if (lane == kLanesPerPair - 1) {
-                    const uint32_t j = t - (kLanesPerPair - 1);  // lane 15 is at column t - 15 >= 1 whenever it is active
-                    cM[j] = M[K - 1];
-                    cX[j] = X[K - 1];
-                    cY[j] = Y[K - 1];
-                }
-            };
-            auto step_t = [&](uint32_t t) {
-                if (t & 1u)
-                    step(t, aM, aX, aY, bM, bX, bY);
-                else
-                    step(t, bM, bX, bY, aM, aX, aY);
-            };
-
-            carry_load(0);
-            uint32_t t = 1;
-            const uint32_t Tfill = Tmax < (uint32_t)(kLanesPerPair - 1) ? Tmax : (uint32_t)(kLanesPerPair - 1);
-            for (; t <= Tfill; ++t) {
-                if ((t & 31u) == 1u) reload(t);
-                if ((t > lane) && (t <= Tg)) step_t(t);
             }
-            for (; t <= Tmin; ++t) {
-                if ((t & 31u) == 1u) reload(t);
-                step_t(t);
-            }
-            for (; t <= Tmax; ++t) {
-                if ((t & 31u) == 1u) reload(t);
-                if (t <= Tg) step_t(t);
-            }
-            // the next stripe of this wave reads what lane 15 just wrote: drain the stores first
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();  // carry columns written in this superstep are visible to the team before the next one
         }
-        if (valid && lane == kLanesPerPair - 1) reinterpret_cast<T *>(a.out_raw)[pair] = sumM + sumX;
     }
 }
 
@@ -592,32 +668,47 @@ hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const Kernel
     return uniform_gcp ? launch_k<float, true, 1>(rows_per_lane, a, s) : launch_k<float, false, 1>(rows_per_lane, a, s);
 }
 
-template <typename T, int K>
-static hipError_t launch_striped_t(bool uniform_gcp, const KernelArgs &a, void *carry, uint32_t carry_stride, uint32_t blocks,
-                                   hipStream_t s)
+template <typename T, int K, bool UG, int WP>
+static hipError_t launch_team_one(const KernelArgs &a, void *carry, uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
-    const size_t shmem = 4u * a.lds_words_per_group * sizeof(uint32_t);
-    if (uniform_gcp)
-        hipLaunchKernelGGL((pairhmm_striped_kernel<T, K, true>), dim3(blocks), dim3(64), shmem, s, a, static_cast<T *>(carry),
-                           carry_stride);
-    else
-        hipLaunchKernelGGL((pairhmm_striped_kernel<T, K, false>), dim3(blocks), dim3(64), shmem, s, a, static_cast<T *>(carry),
-                           carry_stride);
+    const size_t shmem = team_lds_bytes(a.lds_words_per_group, WP, sizeof(T));
+    auto kern = pairhmm_team_kernel<T, K, UG, WP>;
+    if (shmem > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(shmem));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(teams), dim3(64 * WP), shmem, s, a, static_cast<T *>(carry), carry_stride);
     return hipGetLastError();
 }
 
-hipError_t launch_striped_f32(bool uniform_gcp, const KernelArgs &a, float *carry, uint32_t carry_stride, uint32_t blocks,
-                              hipStream_t s)
+template <typename T, int K>
+static hipError_t launch_team_t(bool ug, int waves_per_team, const KernelArgs &a, void *carry, uint32_t carry_stride,
+                                uint32_t teams, hipStream_t s)
 {
     if (a.n_pairs == 0) return hipSuccess;
-    return launch_striped_t<float, kStripedRowsF32>(uniform_gcp, a, carry, carry_stride, blocks, s);
+    if (waves_per_team == 8)
+        return ug ? launch_team_one<T, K, true, 8>(a, carry, carry_stride, teams, s)
+                  : launch_team_one<T, K, false, 8>(a, carry, carry_stride, teams, s);
+    if (waves_per_team == 4)
+        return ug ? launch_team_one<T, K, true, 4>(a, carry, carry_stride, teams, s)
+                  : launch_team_one<T, K, false, 4>(a, carry, carry_stride, teams, s);
+    if (waves_per_team == 1)
+        return ug ? launch_team_one<T, K, true, 1>(a, carry, carry_stride, teams, s)
+                  : launch_team_one<T, K, false, 1>(a, carry, carry_stride, teams, s);
+    return hipErrorInvalidValue;
 }
 
-hipError_t launch_striped_f64(bool uniform_gcp, const KernelArgs &a, double *carry, uint32_t carry_stride, uint32_t blocks,
-                              hipStream_t s)
+hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, const KernelArgs &a, float *carry, uint32_t carry_stride,
+                              uint32_t teams, hipStream_t s)
 {
-    if (a.n_pairs == 0) return hipSuccess;
-    return launch_striped_t<double, kStripedRowsF64>(uniform_gcp, a, carry, carry_stride, blocks, s);
+    return launch_team_t<float, kStripedRowsF32>(uniform_gcp, waves_per_team, a, carry, carry_stride, teams, s);
+}
+
+hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, const KernelArgs &a, double *carry, uint32_t carry_stride,
+                              uint32_t teams, hipStream_t s)
+{
+    return launch_team_t<double, kStripedRowsF64>(uniform_gcp, waves_per_team, a, carry, carry_stride, teams, s);
 }
 
 hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
