@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librovaca_pairhmm_hip.so")
+LIB_PATH = os.environ.get("ROVACA_AMD_HIP_LIB") or os.path.join(_HERE, "lib", "librovaca_pairhmm_hip.so")  # override: tuning only
 _LIB = None
 
 PHMM_OK = 0

@@ -125,9 +125,10 @@ struct Rows
     __device__ __forceinline__ T p_xx(int k) const { return p_xx_r[UG ? 0 : k]; }
 };
 
-// Occupancy target (waves per SIMD) handed to the register allocator: the UG kernel at K = 10 (150-bp reads) needs
-// 131 VGPRs unconstrained, 3 more than the 128 that admit a fourth wave.
-#define PHMM_MIN_WAVES(K, UG) (((UG) && (K) <= 10) ? 4 : 1)
+// Occupancy target (waves per SIMD) handed to the register allocator, from measurements per K (tools/bench_by_k.py): the UG
+// kernel at K = 10 (150-bp reads) needs 131 VGPRs unconstrained, 3 more than the 128 that admit a fourth wave; K = 11 still
+// wins at 4 waves with a few spills outside the steady loop; K = 12..14 run best at 3 waves.
+#define PHMM_MIN_WAVES(K, UG) (((UG) && (K) <= 11) ? 4 : ((UG) && (K) <= 14) ? 3 : 1)
 
 template <typename T, int K, bool UG>
 __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_systolic_kernel(KernelArgs a)
@@ -269,6 +270,9 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_
             tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
             tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
             M[k] = tt * prior;
+            // Keep the rows in program order: measured on MI355X, hipcc's own interleavings of this block run 5-25 %
+            // slower (tools/try_variants.sh), whatever the scheduling strategy.
+            __builtin_amdgcn_sched_barrier(0);
         }
         // Pass 2, top row first: the insertion state chains down the column through the NEW M and X.
         T uM = uM0, uX = uX0;
@@ -278,6 +282,7 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_
             uM = M[k];
             uX = X[k];
         }
+        __builtin_amdgcn_sched_barrier(0);
         sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
         sumX = sumX + X[K - 1];
     };

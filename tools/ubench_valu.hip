@@ -38,7 +38,7 @@ __global__ void k(float* out, int iters, unsigned long long* clk)
 template <int MODE> void run(const char* name, float* out, unsigned long long* clk)
 {
     const int iters = 2000, per_iter = 64;
-    printf("%-34s", name);
+    printf("%-34s", name); fflush(stdout);
     for (int wps : {1, 2, 4, 8}) {
         int threads = 256, blocks = 256 * wps;  // 256 CUs x (wps waves/SIMD x 4 SIMD / 4 waves per block)
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -54,6 +54,47 @@ template <int MODE> void run(const char* name, float* out, unsigned long long* c
         printf("  w%d: %5.3f ipc (%4.2f cyc/instr, %.2f GHz)", wps, ipc, 1.0 / ipc, ghz);
     }
     printf("\n");
+    fflush(stdout);
+}
+
+
+#define SALU2 "s_xor_b64 s[20:21], s[20:21], s[22:23]\n s_nor_b64 s[24:25], s[20:21], s[22:23]\n"
+template <int NS>
+__global__ void ksalu(float* out, int iters, unsigned long long* clk)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b = 0.999f, c = 0.001f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#define BODY(S) asm volatile("v_fma_f32 %0, %0, %8, %9\n" S "v_fma_f32 %1, %1, %8, %9\n" S "v_fma_f32 %2, %2, %8, %9\n" S "v_fma_f32 %3, %3, %8, %9\n" S "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s20", "s21", "s22", "s23", "s24", "s25", "scc");
+        if (NS == 0) { REP8(BODY("")) }
+        if (NS == 2) { REP8(BODY("s_xor_b64 s[20:21], s[20:21], s[22:23]\n")) }   // 4 SALU per 8 VALU
+        if (NS == 4) { REP8(BODY(SALU2)) }                                          // 8 SALU per 8 VALU
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+template <int NS> void run_salu(const char* name, float* out, unsigned long long* clk)
+{
+    const int iters = 2000, per_iter = 64;
+    printf("%-34s", name); fflush(stdout);
+    for (int wps : {1, 2, 4, 8}) {
+        int threads = 256, blocks = 256 * wps;
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(ksalu<NS>, dim3(blocks), dim3(threads), 0, 0, out, 10, clk);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0)); hipLaunchKernelGGL(ksalu<NS>, dim3(blocks), dim3(threads), 0, 0, out, iters, clk); CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long h[2]; CHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+        double ghz = (double)h[0] / ((double)h[1] * 10.0);
+        double winstr = (double)blocks * 4 * iters * per_iter;
+        double cyc = ms * 1e-3 * ghz * 1e9;
+        double ipc = winstr / (256.0 * 4) / cyc;
+        printf("  w%d: %4.2f cyc/VALU (%.2f GHz)", wps, 1.0 / ipc, ghz);
+    }
+    printf("\n");
+    fflush(stdout);
 }
 
 int main()
@@ -68,5 +109,8 @@ int main()
     run<6>("v_mul/fmac_f32_dpp row_shr:1", out, clk);
     run<4>("v_add_co_u32 + v_cndmask_b32", out, clk);
     run<5>("v_fma_f64 (4 indep)", out, clk);
+    run_salu<0>("8 v_fma + 0 SALU", out, clk);
+    run_salu<2>("8 v_fma + 4 SALU (interleaved)", out, clk);
+    run_salu<4>("8 v_fma + 8 SALU (interleaved)", out, clk);
     return 0;
 }
