@@ -42,14 +42,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: the PairHMM engine has no CPU path")
+    device = local_rank % n_dev
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        if n_dev >= world:
+            # one rank per GPU; RCCL carries only the barrier and the max-over-ranks of the wall time
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            # rehearsal on a box with fewer GPUs than ranks (ranks share a card): same code path, gloo for the barrier
+            dist.init_process_group(backend="gloo")
     else:
         dist = None
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device)
 
     from rovaca_amd import capi, synth
 
@@ -61,7 +70,7 @@ def main():
     cells = batch.cells()
     alg_bytes = batch.algorithmic_bytes()
 
-    eng = capi.Engine(local_rank)
+    eng = capi.Engine(device)
     rb = eng.upload(batch)
 
     def barrier():
@@ -85,15 +94,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        on_gpu = dist.get_backend() == "nccl"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        ct = torch.tensor([float(cells)], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)  # every rank generated its own batch: sum the cells actually swept
+        total_cells_all = int(ct.item())
+    else:
+        total_cells_all = cells
 
     raw, l10, st = rb.download()
     out = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
-        total_cells = cells * world
+        total_cells = total_cells_all
         gcups = total_cells * args.steps / elapsed / 1e9
         k_ms = float(np.mean(fp32_ms))  # dominant kernel: the fp32 systolic sweep (all launches of one pass)
         achieved_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
