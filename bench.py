@@ -30,8 +30,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--scale", type=float, default=1.0, help="multiplies the number of regions of the config")
+    ap.add_argument("--chunk-regions", type=int, default=1000, help="regions per resident chunk (c4 streams 12.5 chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -66,12 +67,38 @@ def main():
     cfg = dict(synth.CONFIGS[args.config])
     cfg["seed"] = cfg["seed"] + 1000 * rank
     cfg["n_regions"] = max(1, int(round(cfg["n_regions"] * args.scale)))
-    batch = synth.make_batch(**cfg)
-    cells = batch.cells()
-    alg_bytes = batch.algorithmic_bytes()
+    # the batch is generated and kept resident in chunks (one upload each); a step sweeps every chunk once
+    chunks = []
+    left, k = cfg["n_regions"], 0
+    while left > 0:
+        c = dict(cfg)
+        c["n_regions"] = min(left, args.chunk_regions)
+        c["seed"] = cfg["seed"] + 7919 * k
+        chunks.append(synth.make_batch(**c))
+        left -= c["n_regions"]
+        k += 1
+    batch = chunks[0]
+    cells = sum(b.cells() for b in chunks)
+    alg_bytes = sum(b.algorithmic_bytes() for b in chunks)
+    n_pairs = sum(b.n_pairs for b in chunks)
 
     eng = capi.Engine(device)
-    rb = eng.upload(batch)
+    residents = [eng.upload(b) for b in chunks]
+
+    class _All:  # the step: every resident chunk, in order, on the engine's stream
+        def sweep(self):
+            for r in residents:
+                r.sweep()
+
+        def sweep_timed(self, n):
+            a = c = 0.0
+            for r in residents:
+                x, y = r.sweep_timed(n)
+                a += x
+                c += y
+            return a, c
+
+    rb = _All()
 
     def barrier():
         torch.cuda.synchronize()
@@ -104,7 +131,8 @@ def main():
     else:
         total_cells_all = cells
 
-    raw, l10, st = rb.download()
+    raw, l10, st = residents[0].download()
+    n_rescued = int(st.n_rescued) + sum(int(r.download()[2].n_rescued) for r in residents[1:])
     out = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -124,9 +152,9 @@ def main():
             "metric": "PairHMM GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {batch.n_pairs} pairs/GPU, reads {cfg['read_len']} bp x haps "
+            "config": {"workload": f"{args.config}: {n_pairs} pairs/GPU, reads {cfg['read_len']} bp x haps "
                                    f"{cfg['hap_len']} bp, fp32 + fp64 rescue, regions of {cfg['reads']} reads x "
-                                   f"{cfg['haps']} haps", "pairs_per_gpu": batch.n_pairs, "cells_per_gpu": cells,
+                                   f"{cfg['haps']} haps", "pairs_per_gpu": n_pairs, "resident_chunks": len(chunks), "cells_per_gpu": cells,
                        "parallelism": f"pair-split x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -135,12 +163,14 @@ def main():
             "roofline_valu": {"bound": "fp32-valu", "achieved": round(valu_tflops, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(valu_tflops / FP32_VALU_PEAK_TFLOPS, 5),
                               "kernel_gcups": round(cells / (k_ms * 1e-3) / 1e9, 2), "flops_per_cell": FLOPS_PER_CELL},
-            "rescued_pairs": int(st.n_rescued), "pass_kernel_ms": round(float(np.mean(kern_ms)), 4),
+            "rescued_pairs": n_rescued, "pass_kernel_ms": round(float(np.mean(kern_ms)), 4),
         }
         if world == 1 and not args.no_cpu_baseline:
+            # the first resident chunk (the whole batch for c1/c2/c3) through the CPU path
             out["cpu_baseline"], delta = cpu_baseline(batch, raw, l10, args.cpu_threads)
             out["max_abs_delta_log10_vs_cpu"] = delta
-    rb.release()
+    for r in residents:
+        r.release()
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -20,6 +20,8 @@ CONFIGS = {
     "c1": dict(seed=1, n_regions=1, reads=40, haps=25, read_len=100, hap_len=150),  # 1 000 pairs, 100x150
     "c2": dict(seed=2, n_regions=1000, reads=40, haps=25, read_len=150, hap_len=300),  # 1 000 000 pairs, 150x300
     "c3": dict(seed=3, n_regions=1000, reads=40, haps=25, read_len=(50, 250), hap_len=(100, 500)),  # mixed lengths
+    # WGS-scale stream: 1e8 pairs over 8 GPUs = 12.5 M pairs per GPU with c3's length distribution, consumed in chunks
+    "c4": dict(seed=4, n_regions=12500, reads=40, haps=25, read_len=(50, 250), hap_len=(100, 500)),
     "c5": dict(seed=5, n_regions=40, reads=5, haps=5, read_len=(2000, 10000), hap_len=(2000, 12000)),  # long reads
 }
 
