@@ -40,7 +40,8 @@ template <typename T>
 struct DevBuf
 {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0;    // elements in use
+    size_t cap = 0;  // elements allocated (grow-only, so a context's scratch batch stops allocating after a few calls)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -49,14 +50,23 @@ struct DevBuf
     {
         if (p) (void)hipFree(p);
         p = nullptr;
-        n = 0;
+        n = cap = 0;
     }
     hipError_t alloc(size_t count)
     {
-        reset();
+        if (count <= cap) {
+            n = count;
+            return hipSuccess;
+        }
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = cap = 0;
+        const size_t want = count + count / 4 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+        if (e != hipSuccess) return e;
+        cap = want;
         n = count;
-        if (count == 0) return hipSuccess;
-        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        return hipSuccess;
     }
     hipError_t upload(const T *src, size_t count, hipStream_t s)
     {
@@ -76,6 +86,7 @@ struct phmm_context
     DevBuf<float> ph2pr_f32, mm_f32;
     DevBuf<double> ph2pr_f64, mm_f64;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
 };
 
 struct Bin
@@ -192,6 +203,7 @@ void phmm_destroy(phmm_context *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c->scratch;
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -213,10 +225,8 @@ void phmm_release(phmm_context *c, phmm_resident *rb)
     delete rb;
 }
 
-int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
+static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
 {
-    if (!c || !b || !out) return fail(PHMM_E_INVALID, "phmm_upload: null argument");
-    *out = nullptr;
     if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
         return fail(PHMM_E_INVALID, "phmm_upload: pair_read and pair_hap must both be given or both be NULL");
     const bool cross = b->pair_read == nullptr;
@@ -245,13 +255,9 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
     if (phmm::team_lds_bytes((uint32_t)phmm::kPlanes * phmm::planes_words(max_hap), 8, 8) > 160u * 1024u)
         return fail(PHMM_E_INVALID, "phmm_upload: haplotype of %u bases exceeds the LDS plane budget", max_hap);
 
-    phmm_resident *rb = new (std::nothrow) phmm_resident();
-    if (!rb) return fail(PHMM_E_NOMEM, "phmm_upload: out of host memory");
-    struct Guard
-    {
-        phmm_resident *p;
-        ~Guard() { delete p; }
-    } guard{rb};
+    rb->bins.clear();
+    rb->last_rescued = 0;
+    rb->last_kernel_ms = 0.0;
     rb->n_pairs = n_pairs;
     rb->n_reads = b->n_reads;
     rb->n_haps = b->n_haps;
@@ -370,7 +376,20 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
                                         (uint32_t)slots, rb->planes.p, st));
     }
     HIP_TRY(hipStreamSynchronize(st));  // the host vectors above die at return
-    guard.p = nullptr;
+    return PHMM_OK;
+}
+
+int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
+{
+    if (!c || !b || !out) return fail(PHMM_E_INVALID, "phmm_upload: null argument");
+    *out = nullptr;
+    phmm_resident *rb = new (std::nothrow) phmm_resident();
+    if (!rb) return fail(PHMM_E_NOMEM, "phmm_upload: out of host memory");
+    const int rc = upload_into(c, b, rb);
+    if (rc != PHMM_OK) {
+        delete rb;
+        return rc;
+    }
     *out = rb;
     return PHMM_OK;
 }
@@ -406,7 +425,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
             const uint32_t teams = std::min<uint32_t>((bin.count + 3) / 4, kStripedMaxTeams / wp);
             const uint32_t stride = bin.max_hap_len + 1;
             const size_t need = phmm::team_carry_values(teams, wp, stride);
-            if (rb->carry32.n < need) HIP_TRY(rb->carry32.alloc(need));
+            HIP_TRY(rb->carry32.alloc(need));
             HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, wp, a, rb->carry32.p, stride, teams, c->stream));
         }
     }
@@ -430,7 +449,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     const uint32_t teams = std::min<uint32_t>((n + 3) / 4, kStripedMaxTeams / wp);
     const uint32_t stride = rb->max_hap_len + 1;
     const size_t need = phmm::team_carry_values(teams, wp, stride);
-    if (rb->carry64.n < need) HIP_TRY(rb->carry64.alloc(need));
+    HIP_TRY(rb->carry64.alloc(need));
     phmm::KernelArgs a{};
     a.read_bases = rb->read_bases.p;
     a.read_qual = rb->read_qual.p;
@@ -531,14 +550,18 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
 
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats)
 {
+    if (!c || !b) return fail(PHMM_E_INVALID, "phmm_compute: null argument");
     const auto t0 = std::chrono::steady_clock::now();
-    phmm_resident *rb = nullptr;
-    int rc = phmm_upload(c, b, &rb);
+    if (!c->scratch) {
+        c->scratch = new (std::nothrow) phmm_resident();
+        if (!c->scratch) return fail(PHMM_E_NOMEM, "phmm_compute: out of host memory");
+    }
+    phmm_resident *rb = c->scratch;
+    int rc = upload_into(c, b, rb);
     if (rc != PHMM_OK) return rc;
     double ms = 0.0;
     rc = phmm_sweep_timed(c, rb, 1, &ms, nullptr);
     if (rc == PHMM_OK) rc = phmm_download(c, rb, out_raw_f32, out_log10, stats);
-    phmm_release(c, rb);
     if (rc == PHMM_OK && stats)
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;

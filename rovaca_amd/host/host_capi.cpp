@@ -39,6 +39,8 @@ uint32_t rovaca_amd_poorly_modelled_reads(const double *lik, const int32_t *read
 // 1 when an MI355X engine was installed into rovaca::call_pairhmm, 0 when no device is visible
 int rovaca_amd_init_pairhmm_ptr_gpu(int device_id) { return rovaca::init_pairhmm_ptr_gpu(device_id) ? 1 : 0; }
 
+void rovaca_amd_batching_stats(uint64_t *regions, uint64_t *submissions) { rovaca::gpu_pairhmm_batching_stats(regions, submissions); }
+
 // One region through rovaca::call_pairhmm (must have been installed).  Inputs are raw BAM-style reads (bases, quals,
 // mapping quality) and haplotype strings; out_hap_read is [n_haps][n_reads] (tail NaN), survivors[k] the original index
 // of the k-th read left in the read vector.  Returns the number of surviving reads, or -1 if the engine is not installed.

@@ -5,9 +5,14 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/pairhmm_hip.h"
@@ -55,6 +60,154 @@ struct ThreadContext
 };
 thread_local ThreadContext t_ctx;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cross-region batching.  The caller evaluates one region per worker thread, synchronously
+// (haplotypecaller_engine.cpp:119-285); a region is 1e7-1e8 cells, i.e. tens of microseconds of MI355X time against a
+// fixed per-submission cost.  Workers therefore hand their flattened region to one dispatcher thread per device and
+// block on it; the dispatcher merges everything that queued up while the previous submission was on the device into ONE
+// phmm_batch (tables concatenated, pair indices rebased), runs it, and hands each worker its slice.  No timer: the batch
+// is whatever arrived during the last device round trip, so a single caller pays one thread hop and 30-128 callers are
+// coalesced automatically.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RegionJob
+{
+    // inputs (owned by the submitting worker, alive until done)
+    const uint8_t *bases, *quals, *gops, *gcps, *hap_bases;
+    const uint32_t *read_off, *read_len, *hap_off, *hap_len;
+    uint32_t n_reads, n_haps;
+    size_t read_bytes, hap_bytes;
+    double *out;  // [read][hap]
+    // completion
+    bool done = false;
+    int status = PHMM_OK;
+};
+
+class RegionBatcher
+{
+public:
+    explicit RegionBatcher(int device) : device_(device), worker_([this] { run(); }) {}
+    ~RegionBatcher()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        worker_.join();
+    }
+    int submit_and_wait(RegionJob &job)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        queue_.push_back(&job);
+        cv_.notify_all();
+        done_cv_.wait(lk, [&] { return job.done; });
+        return job.status;
+    }
+    std::atomic<uint64_t> regions{0}, submissions{0};
+
+private:
+    void run()
+    {
+        phmm_context *ctx = nullptr;
+        if (phmm_create(device_, nullptr, &ctx) != PHMM_OK) {
+            fprintf(stderr, "[rovaca_amd] pairhmm: cannot create a device context: %s\n", phmm_last_error());
+            exit(EXIT_FAILURE);
+        }
+        std::vector<RegionJob *> jobs;
+        std::vector<uint8_t> bases, quals, gops, gcps, haps;
+        std::vector<uint32_t> roff, rlen, hoff, hlen, pr, ph;
+        std::vector<double> out;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+                if (stop_ && queue_.empty()) break;
+                jobs.assign(queue_.begin(), queue_.end());
+                queue_.clear();
+            }
+            // merge: concatenate the tables, rebase the indices, spell the cross products out as one pair list
+            bases.clear();
+            quals.clear();
+            gops.clear();
+            gcps.clear();
+            haps.clear();
+            roff.clear();
+            rlen.clear();
+            hoff.clear();
+            hlen.clear();
+            pr.clear();
+            ph.clear();
+            for (RegionJob *j : jobs) {
+                const uint32_t r0 = (uint32_t)rlen.size(), h0 = (uint32_t)hlen.size();
+                const uint32_t rb = (uint32_t)bases.size(), hb = (uint32_t)haps.size();
+                bases.insert(bases.end(), j->bases, j->bases + j->read_bytes);
+                quals.insert(quals.end(), j->quals, j->quals + j->read_bytes);
+                gops.insert(gops.end(), j->gops, j->gops + j->read_bytes);
+                gcps.insert(gcps.end(), j->gcps, j->gcps + j->read_bytes);
+                haps.insert(haps.end(), j->hap_bases, j->hap_bases + j->hap_bytes);
+                for (uint32_t r = 0; r < j->n_reads; ++r) {
+                    roff.push_back(rb + j->read_off[r]);
+                    rlen.push_back(j->read_len[r]);
+                }
+                for (uint32_t h = 0; h < j->n_haps; ++h) {
+                    hoff.push_back(hb + j->hap_off[h]);
+                    hlen.push_back(j->hap_len[h]);
+                }
+                for (uint32_t r = 0; r < j->n_reads; ++r)
+                    for (uint32_t h = 0; h < j->n_haps; ++h) {
+                        pr.push_back(r0 + r);
+                        ph.push_back(h0 + h);
+                    }
+            }
+            phmm_batch b{};
+            b.n_reads = (uint32_t)rlen.size();
+            b.n_haps = (uint32_t)hlen.size();
+            b.n_pairs = pr.size();
+            b.read_bases = bases.data();
+            b.read_qual = quals.data();
+            b.read_ins = gops.data();
+            b.read_del = gops.data();
+            b.read_gcp = gcps.data();
+            b.read_off = roff.data();
+            b.read_len = rlen.data();
+            b.hap_bases = haps.data();
+            b.hap_off = hoff.data();
+            b.hap_len = hlen.data();
+            b.pair_read = pr.data();
+            b.pair_hap = ph.data();
+            out.resize(pr.size());
+            const int rc = phmm_compute(ctx, &b, nullptr, out.data(), nullptr);
+            regions += jobs.size();
+            submissions += 1;
+            size_t at = 0;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                for (RegionJob *j : jobs) {
+                    const size_t n = (size_t)j->n_reads * j->n_haps;
+                    if (rc == PHMM_OK) memcpy(j->out, out.data() + at, n * sizeof(double));
+                    at += n;
+                    j->status = rc;
+                    j->done = true;
+                }
+            }
+            done_cv_.notify_all();
+        }
+        phmm_destroy(ctx);
+    }
+
+    int device_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<RegionJob *> queue_;
+    bool stop_ = false;
+    std::thread worker_;
+};
+
+// one per device in use; intentionally never destroyed (their threads would otherwise call into HIP during static teardown)
+std::vector<RegionBatcher *> g_batchers;
+std::atomic<bool> g_batching{false};
+std::atomic<uint32_t> g_next_batcher{0};
+
 }  // namespace
 
 bool init_pairhmm_ptr_gpu(int device_id)
@@ -62,9 +215,31 @@ bool init_pairhmm_ptr_gpu(int device_id)
     const int n = phmm_device_count();
     if (n <= 0 || device_id >= n) return false;
     g_device.store(device_id);
+    const char *env = getenv("ROVACA_AMD_PAIRHMM_BATCHING");
+    const bool batching = !(env && env[0] == '0');
+    if (batching && g_batchers.empty()) {
+        if (device_id >= 0) {
+            g_batchers.push_back(new RegionBatcher(device_id));
+        }
+        else {
+            for (int d = 0; d < n; ++d) g_batchers.push_back(new RegionBatcher(d));
+        }
+    }
+    g_batching.store(batching);
     call_pairhmm = call_gpu_pairhmm;
     g_active.store(true);
     return true;
+}
+
+void gpu_pairhmm_batching_stats(uint64_t *regions, uint64_t *submissions)
+{
+    uint64_t r = 0, s = 0;
+    for (RegionBatcher *b : g_batchers) {
+        r += b->regions.load();
+        s += b->submissions.load();
+    }
+    if (regions) *regions = r;
+    if (submissions) *submissions = s;
 }
 
 bool gpu_pairhmm_active() { return g_active.load(); }
@@ -133,7 +308,17 @@ DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32
     b.hap_off = hap_off.data();
     b.hap_len = hap_len.data();
     std::vector<double> likelihood_array(reads_num * haplotypes_num);  // [read][hap]
-    if (phmm_compute(t_ctx.get(), &b, nullptr, likelihood_array.data(), nullptr) != PHMM_OK) {
+    int rc;
+    if (g_batching.load() && !g_batchers.empty()) {
+        RegionJob job{bases.data(), quals.data(), gops.data(), gcps.data(), hap_bases.data(), read_off.data(), read_len.data(),
+                      hap_off.data(), hap_len.data(), (uint32_t)reads_num, (uint32_t)haplotypes_num, total, hap_total,
+                      likelihood_array.data()};
+        rc = g_batchers[g_next_batcher.fetch_add(1) % g_batchers.size()]->submit_and_wait(job);
+    }
+    else {
+        rc = phmm_compute(t_ctx.get(), &b, nullptr, likelihood_array.data(), nullptr);
+    }
+    if (rc != PHMM_OK) {
         fprintf(stderr, "[rovaca_amd] pairhmm: device evaluation failed: %s\n", phmm_last_error());
         exit(EXIT_FAILURE);
     }

@@ -37,6 +37,10 @@ extern DoubleVector2D (*call_pairhmm)(const HaplotypeVector &hs, ReadVector &rs,
 // own.  `device_id` < 0 means round-robin over all visible devices per calling thread.
 bool init_pairhmm_ptr_gpu(int device_id = -1);
 
+// Regions evaluated and device submissions made by the cross-region batcher: workers that call
+// call_pairhmm concurrently are coalesced into one device batch per round trip.  ROVACA_AMD_PAIRHMM_BATCHING=0 disables it.
+void gpu_pairhmm_batching_stats(uint64_t *regions, uint64_t *submissions);
+
 // true once init_pairhmm_ptr_gpu succeeded (the caller skips its AVX-512 read pre-sort, haplotypecaller_engine.cpp:245-248)
 bool gpu_pairhmm_active();
 

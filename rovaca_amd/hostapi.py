@@ -18,7 +18,7 @@ PCR = {"NONE": 0, "HOSTILE": 1, "AGGRESSIVE": 2, "CONSERVATIVE": 3}  # common/en
 
 EXPORTS = ("rovaca_amd_modify_read_qualities", "rovaca_amd_tandem_repeat_length", "rovaca_amd_apply_pcr_error_model",
            "rovaca_amd_normalize_likelihoods", "rovaca_amd_poorly_modelled_reads", "rovaca_amd_init_pairhmm_ptr_gpu",
-           "rovaca_amd_call_region")
+           "rovaca_amd_call_region", "rovaca_amd_batching_stats")
 
 
 def lib():
@@ -43,8 +43,17 @@ def lib():
     L.rovaca_amd_call_region.argtypes = [u8p, u8p, u32p, u32p, u8p, C.c_uint32, u8p, u32p, u32p, C.c_uint32, C.c_int32,
                                          C.c_int, f64p, u32p]
     L.rovaca_amd_call_region.restype = C.c_int32
+    L.rovaca_amd_batching_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rovaca_amd_batching_stats.restype = None
     _LIB = L
     return L
+
+
+def batching_stats():
+    """(regions evaluated, device submissions) of the cross-region batcher."""
+    r, s = C.c_uint64(), C.c_uint64()
+    lib().rovaca_amd_batching_stats(C.byref(r), C.byref(s))
+    return int(r.value), int(s.value)
 
 
 def init_pairhmm_ptr_gpu(device=-1):

@@ -69,3 +69,37 @@ def test_concurrent_workers():
     [t.join() for t in th]
     for (a, sa), (b, sb) in zip(single, out):
         assert np.array_equal(sa, sb) and np.array_equal(a, b, equal_nan=True)
+
+
+def test_cross_region_batching_coalesces_concurrent_workers():
+    # 32 workers x 8 regions each; the dispatcher must merge concurrent submissions into fewer
+    # device batches and every worker must still get exactly its own region's matrix
+    import threading
+    import time
+    regions = [_raw_region(100 + i, reads=24, haps=6, read_len=(60, 150), hap_len=280, bad_reads=2) for i in range(32)]
+    want = []
+    for r in regions:
+        n_reads, n_haps = len(r[3]), len(r[7])
+        w = np.full(n_haps * n_reads, np.nan)
+        ws = np.zeros(n_reads, np.uint32)
+        k = oracle.lib().phmm_oracle_call_region(r[0], r[1], r[2], r[3], r[4], n_reads, r[5], r[6], r[7], n_haps, 18, 3, w, ws)
+        want.append((w.reshape(n_haps, n_reads), ws[:k].copy()))
+    r0, s0 = hostapi.batching_stats()
+    errors = []
+
+    def work(i):
+        for _ in range(8):
+            got, surv = hostapi.call_region(*regions[i])
+            if not (np.array_equal(surv, want[i][1]) and np.array_equal(got, want[i][0], equal_nan=True)):
+                errors.append(i)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(32)]
+    t0 = time.perf_counter()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    r1, s1 = hostapi.batching_stats()
+    assert not errors
+    assert r1 - r0 == 32 * 8
+    assert s1 - s0 < r1 - r0, "no coalescing happened"
+    print(f"256 regions from 32 workers in {dt*1e3:.1f} ms: {s1 - s0} device submissions")
