@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PHMM_ABI_VERSION 1
+#define PHMM_ABI_VERSION 2
 
 /* status codes (0 = ok).  Nothing is thrown across this boundary. */
 enum {
@@ -41,6 +41,21 @@ enum {
 
 typedef struct phmm_context phmm_context; /* device, stream, lookup tables, staging pool */
 typedef struct phmm_resident phmm_resident; /* a batch uploaded to HBM, length-binned, ready to sweep */
+
+/* Optional device-side read preparation: what decompression_data does on the host per read
+ * (pairhmm_internal.cpp:413-448) -- base-quality modification and the PCR indel model -- done by a GPU kernel instead.
+ * When phmm_batch.prep is non-NULL, read_qual holds the RAW base qualities (ReadRecord::qual()), and read_ins / read_del /
+ * read_gcp are ignored (may be NULL): the engine derives
+ *     qual = min(qual, mapq); qual < min_quality_threshold -> 6                 (pairhmm_internal.cpp:434-439, adapter.h:5)
+ *     ins = del = gap_open capped by the PCR table at the tandem-repeat length    (pairhmm_internal.cpp:65-159, adapter.h:13-15)
+ *     gcp = gap_cont                                                             (read_record.cpp:205-210) */
+typedef struct phmm_read_prep {
+    const uint8_t *read_mapq;      /* [n_reads] mapping quality */
+    int32_t min_quality_threshold; /* --base-quality-score-threshold, default 18 */
+    int32_t pcr_model;             /* 0 NONE, 1 HOSTILE, 2 AGGRESSIVE, 3 CONSERVATIVE (common/enum.h:8) */
+    uint8_t gap_open;              /* 45, read_record.cpp:191-196 */
+    uint8_t gap_cont;              /* 10, read_record.cpp:205-210 */
+} phmm_read_prep;
 
 /* A batch of N (read, haplotype) pairs over a read table and a haplotype table.
  * Replaces the per-pair ::TestCase the reference builds at pairhmm_internal.cpp:569-576 / :675-682. */
@@ -63,6 +78,8 @@ typedef struct phmm_batch {
     /* pair list; both NULL means the full cross product in (read, hap) order: pair p = (p / n_haps, p % n_haps) */
     const uint32_t *pair_read;
     const uint32_t *pair_hap;
+    /* NULL: the read table above is already prepared (::TestCase semantics).  Non-NULL: see phmm_read_prep. */
+    const phmm_read_prep *prep;
 } phmm_batch;
 
 typedef struct phmm_stats {
@@ -99,6 +116,8 @@ int phmm_sweep(phmm_context *ctx, phmm_resident *rb);
 int phmm_sweep_timed(phmm_context *ctx, phmm_resident *rb, int iters, double *ms_per_pass, double *fp32_ms_per_pass);
 /* copy results of the last pass back and finalize on the host (log10f/log10 in glibc, as the reference does) */
 int phmm_download(phmm_context *ctx, phmm_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats);
+/* diagnostic: the prepared read table as the kernels see it (after phmm_read_prep, if any); any pointer may be NULL */
+int phmm_download_read_table(phmm_context *ctx, phmm_resident *rb, uint8_t *qual, uint8_t *ins, uint8_t *del, uint8_t *gcp);
 int phmm_synchronize(phmm_context *ctx);
 void phmm_release(phmm_context *ctx, phmm_resident *rb);
 

@@ -17,7 +17,7 @@ MM_TABLE_SIZE = 32640
 
 EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy", "phmm_last_error", "phmm_compute",
            "phmm_upload", "phmm_sweep", "phmm_sweep_timed", "phmm_download", "phmm_synchronize", "phmm_release",
-           "phmm_get_tables")
+           "phmm_get_tables", "phmm_download_read_table")
 
 
 class PhmmBatch(C.Structure):
@@ -25,7 +25,12 @@ class PhmmBatch(C.Structure):
                 ("read_bases", C.c_void_p), ("read_qual", C.c_void_p), ("read_ins", C.c_void_p),
                 ("read_del", C.c_void_p), ("read_gcp", C.c_void_p), ("read_off", C.c_void_p), ("read_len", C.c_void_p),
                 ("hap_bases", C.c_void_p), ("hap_off", C.c_void_p), ("hap_len", C.c_void_p),
-                ("pair_read", C.c_void_p), ("pair_hap", C.c_void_p)]
+                ("pair_read", C.c_void_p), ("pair_hap", C.c_void_p), ("prep", C.c_void_p)]
+
+
+class PhmmReadPrep(C.Structure):
+    _fields_ = [("read_mapq", C.c_void_p), ("min_quality_threshold", C.c_int32), ("pcr_model", C.c_int32),
+                ("gap_open", C.c_uint8), ("gap_cont", C.c_uint8)]
 
 
 class PhmmStats(C.Structure):
@@ -75,6 +80,8 @@ def lib():
     L.phmm_synchronize.restype = C.c_int
     L.phmm_release.argtypes = [C.c_void_p, C.c_void_p]
     L.phmm_release.restype = None
+    L.phmm_download_read_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.phmm_download_read_table.restype = C.c_int
     L.phmm_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.phmm_get_tables.restype = C.c_int
     _LIB = L
@@ -90,8 +97,17 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def _c_batch(b, cross=False):
+def _c_batch(b, cross=False, prep=None):
+    """prep: None, or (read_mapq uint8 array, min_quality_threshold, pcr_model[, gap_open, gap_cont]) for device-side
+    quality modification + PCR indel model; b.read_qual then holds raw qualities and b.read_ins/del/gcp are ignored."""
     cb = PhmmBatch()
+    cb._keep = None
+    if prep is not None:
+        mq = np.ascontiguousarray(prep[0], np.uint8)
+        pp = PhmmReadPrep(_ptr(mq), int(prep[1]), int(prep[2]), int(prep[3]) if len(prep) > 3 else 45,
+                          int(prep[4]) if len(prep) > 4 else 10)
+        cb._keep = (mq, pp)
+        cb.prep = C.cast(C.pointer(pp), C.c_void_p)
     cb.n_reads, cb.n_haps, cb.n_pairs = b.n_reads, b.n_haps, b.n_pairs
     for k in ("read_bases", "read_qual", "read_ins", "read_del", "read_gcp", "read_off", "read_len", "hap_bases",
               "hap_off", "hap_len"):
@@ -130,6 +146,13 @@ class Resident:
         _check(lib().phmm_download(self.engine.handle, self.handle, _ptr(raw), _ptr(l10), C.byref(st)), "phmm_download")
         return raw, l10, st
 
+    def read_table(self):
+        """(qual, ins, del, gcp) as the kernels see them -- diagnostic, used to check device-side read preparation."""
+        out = [np.zeros(self.read_bytes, np.uint8) for _ in range(4)]
+        _check(lib().phmm_download_read_table(self.engine.handle, self.handle, *[_ptr(a) for a in out]),
+               "phmm_download_read_table")
+        return out
+
     def release(self):
         if self.handle:
             lib().phmm_release(self.engine.handle, self.handle)
@@ -151,9 +174,9 @@ class Engine:
         _check(L.phmm_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)), "phmm_create")
         self.handle = h
 
-    def compute(self, batch, cross=False):
+    def compute(self, batch, cross=False, prep=None):
         """Host buffers in, (raw_f32, log10, stats) out."""
-        cb = _c_batch(batch, cross)
+        cb = _c_batch(batch, cross, prep)
         n = batch.n_reads * batch.n_haps if cross else batch.n_pairs
         raw = np.zeros(n, np.float32)
         l10 = np.zeros(n, np.float64)
@@ -161,11 +184,13 @@ class Engine:
         _check(lib().phmm_compute(self.handle, C.byref(cb), _ptr(raw), _ptr(l10), C.byref(st)), "phmm_compute")
         return raw, l10, st
 
-    def upload(self, batch, cross=False):
-        cb = _c_batch(batch, cross)
+    def upload(self, batch, cross=False, prep=None):
+        cb = _c_batch(batch, cross, prep)
         h = C.c_void_p()
         _check(lib().phmm_upload(self.handle, C.byref(cb), C.byref(h)), "phmm_upload")
-        return Resident(self, h, batch.n_reads * batch.n_haps if cross else batch.n_pairs)
+        r = Resident(self, h, batch.n_reads * batch.n_haps if cross else batch.n_pairs)
+        r.read_bytes = int(batch.read_bases.shape[0])
+        return r
 
     def synchronize(self):
         _check(lib().phmm_synchronize(self.handle), "phmm_synchronize")

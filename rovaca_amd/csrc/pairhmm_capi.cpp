@@ -120,7 +120,8 @@ struct phmm_resident
     uint64_t n_pairs = 0, cells = 0;
     uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
     bool uniform_gcp = false;
-    DevBuf<uint8_t> read_bases, read_qual, read_ins, read_del, read_gcp, hap_bases;
+    DevBuf<uint8_t> read_bases, read_qual, read_ins, read_del, read_gcp, hap_bases, read_mapq;
+    bool del_aliases_ins = false;  // device-prepared batches: the deletion gap-open IS the insertion array (pairhmm_internal.cpp:425)
     DevBuf<uint32_t> read_off, read_len, hap_off, hap_len, pair_read, pair_hap, order;
     DevBuf<uint32_t> planes, plane_off, word_owner;
     DevBuf<float> raw32;
@@ -232,9 +233,14 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     const bool cross = b->pair_read == nullptr;
     const uint64_t n_pairs = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
     if (n_pairs > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_upload: more than 2^32 pairs in one batch");
-    if (n_pairs && (!b->read_bases || !b->read_qual || !b->read_ins || !b->read_del || !b->read_gcp || !b->read_off ||
-                    !b->read_len || !b->hap_bases || !b->hap_off || !b->hap_len))
+    const phmm_read_prep *prep = b->prep;
+    if (n_pairs && (!b->read_bases || !b->read_qual || !b->read_off || !b->read_len || !b->hap_bases || !b->hap_off ||
+                    !b->hap_len))
         return fail(PHMM_E_INVALID, "phmm_upload: null table pointer");
+    if (n_pairs && !prep && (!b->read_ins || !b->read_del || !b->read_gcp))
+        return fail(PHMM_E_INVALID, "phmm_upload: null gap-penalty array (and no phmm_read_prep given)");
+    if (prep && (!prep->read_mapq || prep->pcr_model < 0 || prep->pcr_model > 3))
+        return fail(PHMM_E_INVALID, "phmm_upload: bad phmm_read_prep");
     HIP_TRY(hipSetDevice(c->device));
 
     // ---- validate the tables, find extents ----
@@ -319,7 +325,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     // the Rovaca case -- one gap-continuation penalty for every base and deletion gap-open == insertion gap-open
     // (read_record.cpp:205-210, pairhmm_internal.cpp:425) -- selects the kernel variant that shares those constants
     bool ug = read_bytes > 0;
-    {
+    if (!prep) {
         const uint8_t c0 = read_bytes ? (b->read_gcp[b->read_off[0]] & 127) : 0;
         for (uint32_t r = 0; r < b->n_reads && ug; ++r) {
             const uint8_t *g = b->read_gcp + b->read_off[r];
@@ -352,9 +358,17 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     hipStream_t st = c->stream;
     HIP_TRY(rb->read_bases.upload(b->read_bases, read_bytes, st));
     HIP_TRY(rb->read_qual.upload(b->read_qual, read_bytes, st));
-    HIP_TRY(rb->read_ins.upload(b->read_ins, read_bytes, st));
-    HIP_TRY(rb->read_del.upload(b->read_del, read_bytes, st));
-    HIP_TRY(rb->read_gcp.upload(b->read_gcp, read_bytes, st));
+    rb->del_aliases_ins = prep != nullptr;
+    if (prep) {
+        HIP_TRY(rb->read_ins.alloc(read_bytes));
+        HIP_TRY(rb->read_gcp.alloc(read_bytes));
+        HIP_TRY(rb->read_mapq.upload(prep->read_mapq, b->n_reads, st));
+    }
+    else {
+        HIP_TRY(rb->read_ins.upload(b->read_ins, read_bytes, st));
+        HIP_TRY(rb->read_del.upload(b->read_del, read_bytes, st));
+        HIP_TRY(rb->read_gcp.upload(b->read_gcp, read_bytes, st));
+    }
     HIP_TRY(rb->read_off.upload(b->read_off, b->n_reads, st));
     HIP_TRY(rb->read_len.upload(b->read_len, b->n_reads, st));
     HIP_TRY(rb->hap_bases.upload(b->hap_bases, hap_bytes, st));
@@ -370,6 +384,10 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     HIP_TRY(rb->raw64.alloc(n_pairs));
     HIP_TRY(rb->rescue_list.alloc(n_pairs));
     HIP_TRY(rb->rescue_count.alloc(1));
+    if (prep && b->n_reads)  // H3 + H4 on the device, in place on the uploaded raw qualities
+        HIP_TRY(phmm::launch_prep_reads(rb->read_bases.p, rb->read_qual.p, rb->read_ins.p, rb->read_gcp.p, rb->read_off.p,
+                                        rb->read_len.p, rb->read_mapq.p, b->n_reads, prep->min_quality_threshold,
+                                        prep->pcr_model, prep->gap_open, prep->gap_cont, st));
     if (n_pairs) {
         HIP_TRY(hipMemsetAsync(rb->raw64.p, 0, n_pairs * sizeof(double), st));
         HIP_TRY(phmm::launch_hap_planes(rb->hap_bases.p, rb->hap_off.p, rb->hap_len.p, rb->plane_off.p, rb->word_owner.p,
@@ -401,7 +419,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.read_bases = rb->read_bases.p;
         a.read_qual = rb->read_qual.p;
         a.read_ins = rb->read_ins.p;
-        a.read_del = rb->read_del.p;
+        a.read_del = rb->del_aliases_ins ? rb->read_ins.p : rb->read_del.p;
         a.read_gcp = rb->read_gcp.p;
         a.read_off = rb->read_off.p;
         a.read_len = rb->read_len.p;
@@ -454,7 +472,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     a.read_bases = rb->read_bases.p;
     a.read_qual = rb->read_qual.p;
     a.read_ins = rb->read_ins.p;
-    a.read_del = rb->read_del.p;
+    a.read_del = rb->del_aliases_ins ? rb->read_ins.p : rb->read_del.p;
     a.read_gcp = rb->read_gcp.p;
     a.read_off = rb->read_off.p;
     a.read_len = rb->read_len.p;
@@ -545,6 +563,20 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
         stats->n_launches = (uint32_t)rb->bins.size();
         stats->max_rows_per_lane = rb->bins.empty() ? 0 : (uint32_t)rb->bins.back().rows_per_lane;
     }
+    return PHMM_OK;
+}
+
+int phmm_download_read_table(phmm_context *c, phmm_resident *rb, uint8_t *qual, uint8_t *ins, uint8_t *del, uint8_t *gcp)
+{
+    if (!c || !rb) return fail(PHMM_E_INVALID, "phmm_download_read_table: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = rb->read_qual.n;
+    const uint8_t *dp = rb->del_aliases_ins ? rb->read_ins.p : rb->read_del.p;
+    if (qual && n) HIP_TRY(hipMemcpyAsync(qual, rb->read_qual.p, n, hipMemcpyDeviceToHost, c->stream));
+    if (ins && n) HIP_TRY(hipMemcpyAsync(ins, rb->read_ins.p, n, hipMemcpyDeviceToHost, c->stream));
+    if (del && n) HIP_TRY(hipMemcpyAsync(del, dp, n, hipMemcpyDeviceToHost, c->stream));
+    if (gcp && n) HIP_TRY(hipMemcpyAsync(gcp, rb->read_gcp.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return PHMM_OK;
 }
 

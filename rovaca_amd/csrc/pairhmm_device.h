@@ -57,6 +57,9 @@ inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t car
 hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
                              const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,
                              hipStream_t s);
+hipError_t launch_prep_reads(const uint8_t *read_bases, uint8_t *read_qual, uint8_t *read_gop, uint8_t *read_gcp,
+                             const uint32_t *read_off, const uint32_t *read_len, const uint8_t *read_mapq, uint32_t n_reads,
+                             int32_t min_q, int32_t pcr_model, uint8_t gap_open, uint8_t gap_cont, hipStream_t s);
 hipError_t launch_collect_rescue(const float *raw, uint32_t n_pairs, uint32_t *list, uint32_t *count, uint32_t capacity,
                                  hipStream_t s);
 

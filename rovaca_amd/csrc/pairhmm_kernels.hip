@@ -632,6 +632,89 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
     }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// device-side read preparation: H3 quality modification and H4 PCR indel model, one workgroup
+// per read, one thread per base.  Integer work, exact.  Follows pairhmm_internal.cpp:434-439 and :65-159 / :195-229
+// including the quirks the host adapter documents (rovaca_amd/host/pairhmm_host_logic.cpp).
+// ----------------------------------------------------------------------------------------------------
+__device__ int32_t count_tiled_units_dev(const uint8_t *unit, int32_t ulen, const uint8_t *text, int32_t tlen, bool from_front)
+{
+    if (tlen == 0) return 0;
+    int32_t copies = 0;
+    const int32_t last = tlen - ulen;
+    if (from_front) {
+        for (int32_t at = 0; at <= last; at += ulen, ++copies) {
+            bool same = true;
+            for (int32_t i = 0; i < ulen; ++i) same = same && (text[at + i] == unit[i]);
+            if (!same) break;
+        }
+    }
+    else {
+        for (int32_t at = last; at >= 0; at -= ulen, ++copies) {
+            bool same = true;
+            for (int32_t i = 0; i < ulen; ++i) same = same && (text[at + i] == unit[i]);
+            if (!same) break;
+        }
+    }
+    return copies;
+}
+
+__device__ int32_t tandem_repeat_length_dev(const uint8_t *bases, int32_t len, int32_t offset)
+{
+    const int32_t prefix = offset + 1;
+    int32_t backward = 0;
+    for (int32_t unit = 1; unit <= 8 && unit <= prefix; ++unit) {
+        backward = count_tiled_units_dev(bases + prefix - unit, unit, bases, prefix, false);
+        if (backward > 1) break;
+    }
+    int32_t total = backward;
+    if (offset < len - 1) {
+        const int32_t suffix = len - prefix;
+        int32_t forward = 0, fw_unit = 1;
+        for (int32_t unit = 1; unit <= 8 && unit <= suffix; ++unit) {
+            forward = count_tiled_units_dev(bases + prefix, unit, bases + prefix, suffix, true);
+            if (forward > 1) {
+                fw_unit = unit;
+                break;
+            }
+        }
+        backward = count_tiled_units_dev(bases + prefix, fw_unit, bases, prefix, false);
+        total = backward + forward;
+    }
+    return total < 20 ? total : 20;
+}
+
+__constant__ uint8_t kPcrCap[4][21] = {
+    {255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255},
+    {40, 40, 39, 38, 37, 36, 34, 32, 28, 23, 17, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10},   // HOSTILE      adapter.h:13
+    {40, 40, 40, 39, 39, 39, 38, 38, 37, 37, 36, 35, 34, 33, 32, 30, 28, 26, 23, 20, 17},   // AGGRESSIVE   adapter.h:14
+    {40, 40, 40, 40, 39, 39, 39, 39, 39, 38, 38, 38, 37, 37, 37, 36, 36, 35, 34, 33, 33}};  // CONSERVATIVE adapter.h:15
+
+__global__ void prep_reads_kernel(const uint8_t *__restrict__ read_bases, uint8_t *__restrict__ read_qual,
+                                  uint8_t *__restrict__ read_gop, uint8_t *__restrict__ read_gcp,
+                                  const uint32_t *__restrict__ read_off, const uint32_t *__restrict__ read_len,
+                                  const uint8_t *__restrict__ read_mapq, int32_t min_q, int32_t pcr_model, uint8_t gap_open,
+                                  uint8_t gap_cont)
+{
+    const uint32_t r = blockIdx.x;
+    const uint32_t off = read_off[r], n = read_len[r];
+    const uint8_t mq = read_mapq[r];
+    const uint8_t *bases = read_bases + off;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint8_t q = read_qual[off + i];
+        q = q < mq ? q : mq;
+        q = (int32_t)q < min_q ? (uint8_t)6 : q;
+        read_qual[off + i] = q;
+        uint8_t g = gap_open;
+        if (pcr_model != 0 && i + 1 < n) {  // the last base keeps its gap-open
+            const uint8_t cap = kPcrCap[pcr_model][tandem_repeat_length_dev(bases, (int32_t)n, (int32_t)i)];
+            g = g < cap ? g : cap;
+        }
+        read_gop[off + i] = g;
+        read_gcp[off + i] = gap_cont;
+    }
+}
+
 // fp32 results below the acceptance threshold (rovaca/common.h:9, MIN_ACCEPTED 1e-28f) are queued for fp64
 __global__ void collect_rescue_kernel(const float *__restrict__ raw, uint32_t n_pairs, uint32_t *__restrict__ list,
                                       uint32_t *__restrict__ count, uint32_t capacity)
@@ -723,6 +806,16 @@ hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, 
     if (n_words == 0) return hipSuccess;
     hipLaunchKernelGGL(hap_planes_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, hap_bases, hap_off, hap_len,
                        plane_off, word_owner, n_words, planes);
+    return hipGetLastError();
+}
+
+hipError_t launch_prep_reads(const uint8_t *read_bases, uint8_t *read_qual, uint8_t *read_gop, uint8_t *read_gcp,
+                             const uint32_t *read_off, const uint32_t *read_len, const uint8_t *read_mapq, uint32_t n_reads,
+                             int32_t min_q, int32_t pcr_model, uint8_t gap_open, uint8_t gap_cont, hipStream_t s)
+{
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_reads_kernel, dim3(n_reads), dim3(128), 0, s, read_bases, read_qual, read_gop, read_gcp, read_off,
+                       read_len, read_mapq, min_q, pcr_model, gap_open, gap_cont);
     return hipGetLastError();
 }
 

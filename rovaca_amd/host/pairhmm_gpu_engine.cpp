@@ -72,10 +72,11 @@ thread_local ThreadContext t_ctx;
 struct RegionJob
 {
     // inputs (owned by the submitting worker, alive until done)
-    const uint8_t *bases, *quals, *gops, *gcps, *hap_bases;
+    const uint8_t *bases, *quals, *mapq, *hap_bases;  // quals are RAW: H3/H4 run on the device (phmm_read_prep)
     const uint32_t *read_off, *read_len, *hap_off, *hap_len;
     uint32_t n_reads, n_haps;
     size_t read_bytes, hap_bytes;
+    int32_t min_q, pcr_model;
     double *out;  // [read][hap]
     // completion
     bool done = false;
@@ -113,8 +114,8 @@ private:
             fprintf(stderr, "[rovaca_amd] pairhmm: cannot create a device context: %s\n", phmm_last_error());
             exit(EXIT_FAILURE);
         }
-        std::vector<RegionJob *> jobs;
-        std::vector<uint8_t> bases, quals, gops, gcps, haps;
+        std::vector<RegionJob *> taken, jobs;
+        std::vector<uint8_t> bases, quals, mapq, haps;
         std::vector<uint32_t> roff, rlen, hoff, hlen, pr, ph;
         std::vector<double> out;
         for (;;) {
@@ -122,75 +123,86 @@ private:
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
                 if (stop_ && queue_.empty()) break;
-                jobs.assign(queue_.begin(), queue_.end());
+                taken.assign(queue_.begin(), queue_.end());
                 queue_.clear();
             }
-            // merge: concatenate the tables, rebase the indices, spell the cross products out as one pair list
-            bases.clear();
-            quals.clear();
-            gops.clear();
-            gcps.clear();
-            haps.clear();
-            roff.clear();
-            rlen.clear();
-            hoff.clear();
-            hlen.clear();
-            pr.clear();
-            ph.clear();
-            for (RegionJob *j : jobs) {
-                const uint32_t r0 = (uint32_t)rlen.size(), h0 = (uint32_t)hlen.size();
-                const uint32_t rb = (uint32_t)bases.size(), hb = (uint32_t)haps.size();
-                bases.insert(bases.end(), j->bases, j->bases + j->read_bytes);
-                quals.insert(quals.end(), j->quals, j->quals + j->read_bytes);
-                gops.insert(gops.end(), j->gops, j->gops + j->read_bytes);
-                gcps.insert(gcps.end(), j->gcps, j->gcps + j->read_bytes);
-                haps.insert(haps.end(), j->hap_bases, j->hap_bases + j->hap_bytes);
-                for (uint32_t r = 0; r < j->n_reads; ++r) {
-                    roff.push_back(rb + j->read_off[r]);
-                    rlen.push_back(j->read_len[r]);
-                }
-                for (uint32_t h = 0; h < j->n_haps; ++h) {
-                    hoff.push_back(hb + j->hap_off[h]);
-                    hlen.push_back(j->hap_len[h]);
-                }
-                for (uint32_t r = 0; r < j->n_reads; ++r)
-                    for (uint32_t h = 0; h < j->n_haps; ++h) {
-                        pr.push_back(r0 + r);
-                        ph.push_back(h0 + h);
+            while (!taken.empty()) {
+                // one device batch per distinct (threshold, PCR model); in practice they are process-wide constants
+                jobs.clear();
+                const int32_t mq = taken.front()->min_q, pm = taken.front()->pcr_model;
+                for (auto it = taken.begin(); it != taken.end();) {
+                    if ((*it)->min_q == mq && (*it)->pcr_model == pm) {
+                        jobs.push_back(*it);
+                        it = taken.erase(it);
                     }
-            }
-            phmm_batch b{};
-            b.n_reads = (uint32_t)rlen.size();
-            b.n_haps = (uint32_t)hlen.size();
-            b.n_pairs = pr.size();
-            b.read_bases = bases.data();
-            b.read_qual = quals.data();
-            b.read_ins = gops.data();
-            b.read_del = gops.data();
-            b.read_gcp = gcps.data();
-            b.read_off = roff.data();
-            b.read_len = rlen.data();
-            b.hap_bases = haps.data();
-            b.hap_off = hoff.data();
-            b.hap_len = hlen.data();
-            b.pair_read = pr.data();
-            b.pair_hap = ph.data();
-            out.resize(pr.size());
-            const int rc = phmm_compute(ctx, &b, nullptr, out.data(), nullptr);
-            regions += jobs.size();
-            submissions += 1;
-            size_t at = 0;
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                for (RegionJob *j : jobs) {
-                    const size_t n = (size_t)j->n_reads * j->n_haps;
-                    if (rc == PHMM_OK) memcpy(j->out, out.data() + at, n * sizeof(double));
-                    at += n;
-                    j->status = rc;
-                    j->done = true;
+                    else {
+                        ++it;
+                    }
                 }
+                // merge: concatenate the tables, rebase the indices, spell the cross products out as one pair list
+                bases.clear();
+                quals.clear();
+                mapq.clear();
+                haps.clear();
+                roff.clear();
+                rlen.clear();
+                hoff.clear();
+                hlen.clear();
+                pr.clear();
+                ph.clear();
+                for (RegionJob *j : jobs) {
+                    const uint32_t r0 = (uint32_t)rlen.size(), h0 = (uint32_t)hlen.size();
+                    const uint32_t rb = (uint32_t)bases.size(), hb = (uint32_t)haps.size();
+                    bases.insert(bases.end(), j->bases, j->bases + j->read_bytes);
+                    quals.insert(quals.end(), j->quals, j->quals + j->read_bytes);
+                    mapq.insert(mapq.end(), j->mapq, j->mapq + j->n_reads);
+                    haps.insert(haps.end(), j->hap_bases, j->hap_bases + j->hap_bytes);
+                    for (uint32_t r = 0; r < j->n_reads; ++r) {
+                        roff.push_back(rb + j->read_off[r]);
+                        rlen.push_back(j->read_len[r]);
+                    }
+                    for (uint32_t h = 0; h < j->n_haps; ++h) {
+                        hoff.push_back(hb + j->hap_off[h]);
+                        hlen.push_back(j->hap_len[h]);
+                    }
+                    for (uint32_t r = 0; r < j->n_reads; ++r)
+                        for (uint32_t h = 0; h < j->n_haps; ++h) {
+                            pr.push_back(r0 + r);
+                            ph.push_back(h0 + h);
+                        }
+                }
+                phmm_read_prep prep{mapq.data(), mq, pm, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
+                phmm_batch b{};
+                b.n_reads = (uint32_t)rlen.size();
+                b.n_haps = (uint32_t)hlen.size();
+                b.n_pairs = pr.size();
+                b.read_bases = bases.data();
+                b.read_qual = quals.data();
+                b.read_off = roff.data();
+                b.read_len = rlen.data();
+                b.hap_bases = haps.data();
+                b.hap_off = hoff.data();
+                b.hap_len = hlen.data();
+                b.pair_read = pr.data();
+                b.pair_hap = ph.data();
+                b.prep = &prep;
+                out.resize(pr.size());
+                const int rc = phmm_compute(ctx, &b, nullptr, out.data(), nullptr);
+                regions += jobs.size();
+                submissions += 1;
+                size_t at = 0;
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    for (RegionJob *j : jobs) {
+                        const size_t n = (size_t)j->n_reads * j->n_haps;
+                        if (rc == PHMM_OK) memcpy(j->out, out.data() + at, n * sizeof(double));
+                        at += n;
+                        j->status = rc;
+                        j->done = true;
+                    }
+                }
+                done_cv_.notify_all();
             }
-            done_cv_.notify_all();
         }
         phmm_destroy(ctx);
     }
@@ -267,19 +279,17 @@ DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32
         total += (size_t)seq_len[i];
         max_len = std::max(max_len, seq_len[i]);
     }
-    std::vector<uint8_t> bases(total), quals(total), gops(total), gcps(total, rovaca_amd::kDefaultGapCont);
+    // H3 (quality modification) and H4 (PCR indel model) run on the device (phmm_read_prep); the host only gathers bytes
+    std::vector<uint8_t> bases(total), quals(total), mapq(reads_num);
     std::vector<uint8_t> tmp(sizeof(Bases) + (size_t)max_len + 1);
     pBases read_bases = reinterpret_cast<pBases>(tmp.data());
-    const int model = static_cast<int>(pcr_option);
     for (size_t i = 0; i < reads_num; ++i) {
         pReadRecord read = rs[i];
         const uint32_t n = read_len[i], o = read_off[i];
         read->decode_base(read_bases);
         memcpy(bases.data() + o, read_bases->data, n);
         memcpy(quals.data() + o, read->qual(), n);
-        rovaca_amd::modify_read_qualities(quals.data() + o, n, read->mapping_quality(), min_quality_threshold);  // :545-550
-        memset(gops.data() + o, rovaca_amd::kDefaultGapOpen, n);                                                 // :552-554
-        if (pcr_option != PcrIndelModel::NONE) rovaca_amd::apply_pcr_error_model(bases.data() + o, gops.data() + o, n, model);
+        mapq[i] = read->mapping_quality();
     }
     // ---- flatten: haplotype table ----
     std::vector<uint32_t> hap_off(haplotypes_num), hap_len(haplotypes_num);
@@ -293,29 +303,29 @@ DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32
     for (size_t j = 0; j < haplotypes_num; ++j) memcpy(hap_bases.data() + hap_off[j], hs[j]->get_display_string()->data, hap_len[j]);
 
     // ---- the device: all reads x all haplotypes, (read, hap) order ----
-    phmm_batch b{};
-    b.n_reads = (uint32_t)reads_num;
-    b.n_haps = (uint32_t)haplotypes_num;
-    b.n_pairs = (uint64_t)reads_num * haplotypes_num;
-    b.read_bases = bases.data();
-    b.read_qual = quals.data();
-    b.read_ins = gops.data();
-    b.read_del = gops.data();  // del gap-open aliases the ins buffer (pairhmm_internal.cpp:559)
-    b.read_gcp = gcps.data();
-    b.read_off = read_off.data();
-    b.read_len = read_len.data();
-    b.hap_bases = hap_bases.data();
-    b.hap_off = hap_off.data();
-    b.hap_len = hap_len.data();
     std::vector<double> likelihood_array(reads_num * haplotypes_num);  // [read][hap]
+    const int model = static_cast<int>(pcr_option);
     int rc;
     if (g_batching.load() && !g_batchers.empty()) {
-        RegionJob job{bases.data(), quals.data(), gops.data(), gcps.data(), hap_bases.data(), read_off.data(), read_len.data(),
+        RegionJob job{bases.data(), quals.data(), mapq.data(), hap_bases.data(), read_off.data(), read_len.data(),
                       hap_off.data(), hap_len.data(), (uint32_t)reads_num, (uint32_t)haplotypes_num, total, hap_total,
-                      likelihood_array.data()};
+                      min_quality_threshold, model, likelihood_array.data()};
         rc = g_batchers[g_next_batcher.fetch_add(1) % g_batchers.size()]->submit_and_wait(job);
     }
     else {
+        phmm_read_prep prep{mapq.data(), min_quality_threshold, model, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
+        phmm_batch b{};
+        b.n_reads = (uint32_t)reads_num;
+        b.n_haps = (uint32_t)haplotypes_num;
+        b.n_pairs = (uint64_t)reads_num * haplotypes_num;
+        b.read_bases = bases.data();
+        b.read_qual = quals.data();
+        b.read_off = read_off.data();
+        b.read_len = read_len.data();
+        b.hap_bases = hap_bases.data();
+        b.hap_off = hap_off.data();
+        b.hap_len = hap_len.data();
+        b.prep = &prep;
         rc = phmm_compute(t_ctx.get(), &b, nullptr, likelihood_array.data(), nullptr);
     }
     if (rc != PHMM_OK) {

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/pairhmm_hip.h but not exported"
     assert set(names) == set(capi.EXPORTS)
-    assert capi.lib().phmm_abi_version() == 1
+    assert capi.lib().phmm_abi_version() == 2
 
 
 def test_product_tables_equal_reference_tables(golden):
@@ -36,7 +36,7 @@ def test_product_tables_equal_reference_tables(golden):
 
 def test_struct_layout_matches_header():
     # phmm_batch: 2 x u32 + u64 + 12 pointers; phmm_stats: 2 x u64 + 2 x f64 + 2 x u32
-    assert ctypes.sizeof(capi.PhmmBatch) == 16 + 12 * 8
+    assert ctypes.sizeof(capi.PhmmBatch) == 16 + 13 * 8
     assert ctypes.sizeof(capi.PhmmStats) == 40
 
 

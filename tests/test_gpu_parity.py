@@ -194,3 +194,52 @@ def test_config5_sample_long_reads(engine):
     assert np.array_equal(l10[fin], ol10[fin])  # fp32-accepted identical, fp64-rescued identical (same op order)
     assert np.array_equal(np.isfinite(l10), fin)
     assert int(st.n_rescued) == int(oresc.sum())
+
+
+def test_device_side_read_preparation_matches_host_logic(engine):
+    # quality modification (H3) and PCR indel model (H4) on the device.  Integer work: the prepared
+    # read table must equal the oracle's byte for byte, and the likelihoods must equal those of the host-prepared batch.
+    from test_host_logic import _reads
+    rng = np.random.default_rng(12)
+    seqs = _reads(rng, 120)  # tandem repeats, homopolymer runs, N, random; lengths 1..259
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    reads, haps, pairs = [], [], []
+    O = oracle.lib()
+    mapq = rng.choice(np.array([60, 60, 29, 12, 0], np.uint8), len(seqs))
+    raw_q = []
+    for i, sq in enumerate(seqs):
+        n = len(sq)
+        q = rng.choice(np.array([2, 11, 17, 18, 25, 37, 41], np.uint8), n)
+        raw_q.append(q)
+        hq = q.copy()
+        O.phmm_oracle_modify_quals(hq, n, int(mapq[i]), 18)
+        g = np.full(n, 45, np.uint8)
+        O.phmm_oracle_apply_pcr_error_model(sq, g, n, 3)
+        reads.append((sq, hq, g, g, np.full(n, 10, np.uint8)))
+        H = n + int(rng.integers(5, 80))
+        hap = acgt[rng.integers(0, 4, H)]
+        st = int(rng.integers(0, H - n + 1))
+        hap[st:st + n] = np.where(sq == ord("N"), ord("A"), sq)
+        haps.append(hap)
+        pairs.append((i, i))
+    host = Batch.from_lists(reads, haps, pairs)
+    for model in (3, 1, 0):
+        if model != 3:  # re-derive the expected gap-opens for the other models
+            gops = []
+            for sq in seqs:
+                g = np.full(len(sq), 45, np.uint8)
+                O.phmm_oracle_apply_pcr_error_model(sq, g, len(sq), model)
+                gops.append(g)
+            host.read_ins = np.concatenate(gops)
+            host.read_del = host.read_ins.copy()
+        raw = Batch(host.read_bases, np.concatenate(raw_q), host.read_ins * 0, host.read_del * 0, host.read_gcp * 0,
+                    host.read_off, host.read_len, host.hap_bases, host.hap_off, host.hap_len, host.pair_read, host.pair_hap)
+        rb = engine.upload(raw, prep=(mapq, 18, model))
+        q, i, d, c = rb.read_table()
+        assert np.array_equal(q, host.read_qual) and np.array_equal(i, host.read_ins) and np.array_equal(d, host.read_del)
+        assert np.array_equal(c, host.read_gcp)
+        rb.sweep()
+        r_dev, l_dev, _ = rb.download()
+        rb.release()
+        r_host, l_host, _ = engine.compute(host)
+        assert np.array_equal(r_dev.view(np.uint32), r_host.view(np.uint32)) and np.array_equal(l_dev, l_host, equal_nan=True)
