@@ -230,11 +230,16 @@ bool init_pairhmm_ptr_gpu(int device_id)
     const char *env = getenv("ROVACA_AMD_PAIRHMM_BATCHING");
     const bool batching = !(env && env[0] == '0');
     if (batching && g_batchers.empty()) {
-        if (device_id >= 0) {
-            g_batchers.push_back(new RegionBatcher(device_id));
-        }
-        else {
-            for (int d = 0; d < n; ++d) g_batchers.push_back(new RegionBatcher(d));
+        // a few dispatchers per device: while one batch is on the device the next one is being merged and uploaded
+        const char *nd = getenv("ROVACA_AMD_PAIRHMM_DISPATCHERS");
+        const int per_device = std::max(1, std::min(8, nd ? atoi(nd) : 3));
+        for (int k = 0; k < per_device; ++k) {
+            if (device_id >= 0) {
+                g_batchers.push_back(new RegionBatcher(device_id));
+            }
+            else {
+                for (int d = 0; d < n; ++d) g_batchers.push_back(new RegionBatcher(d));
+            }
         }
     }
     g_batching.store(batching);
