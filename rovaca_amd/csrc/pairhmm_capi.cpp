@@ -76,6 +76,40 @@ struct DevBuf
     }
 };
 
+// a typed window into the resident batch's single input blob (not owned)
+template <typename T>
+struct DevView
+{
+    T *p = nullptr;
+    size_t n = 0;
+};
+
+// pinned host staging, grow-only
+struct HostBuf
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    HostBuf() = default;
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    ~HostBuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+};
+
 }  // namespace
 
 struct phmm_context
@@ -120,10 +154,15 @@ struct phmm_resident
     uint64_t n_pairs = 0, cells = 0;
     uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
     bool uniform_gcp = false;
-    DevBuf<uint8_t> read_bases, read_qual, read_ins, read_del, read_gcp, hap_bases, read_mapq;
+    // inputs travel as ONE pinned staging buffer and ONE host-to-device copy per upload (a region-sized submission is
+    // latency-bound: fifteen small copies cost more than the sweep); the views below point into `blob`
+    HostBuf stage, out_stage;
+    DevBuf<uint8_t> blob;
+    DevView<uint8_t> read_bases, read_qual, hap_bases, read_mapq;
+    DevView<uint32_t> read_off, read_len, hap_off, hap_len, pair_read, pair_hap, order, plane_off, word_owner;
+    DevBuf<uint8_t> read_ins, read_del, read_gcp;  // uploaded (prepared batches) or written by prep_reads_kernel
     bool del_aliases_ins = false;  // device-prepared batches: the deletion gap-open IS the insertion array (pairhmm_internal.cpp:425)
-    DevBuf<uint32_t> read_off, read_len, hap_off, hap_len, pair_read, pair_hap, order;
-    DevBuf<uint32_t> planes, plane_off, word_owner;
+    DevBuf<uint32_t> planes;
     DevBuf<float> raw32;
     DevBuf<double> raw64;
     DevBuf<uint32_t> rescue_list, rescue_count;
@@ -354,31 +393,59 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
             for (uint32_t w = 0; w < phmm::planes_words(b->hap_len[h]); ++w) owner[s++] = h;
     }
 
-    // ---- upload ----
+    // ---- upload: pack every input into the pinned stage, one copy ----
     hipStream_t st = c->stream;
-    HIP_TRY(rb->read_bases.upload(b->read_bases, read_bytes, st));
-    HIP_TRY(rb->read_qual.upload(b->read_qual, read_bytes, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the previous pass of this resident batch no longer reads the stage or the blob
+    struct Piece
+    {
+        const void *src;
+        size_t bytes, at;
+    };
+    std::vector<Piece> pieces;
+    size_t total = 0;
+    auto reserve = [&](const void *src, size_t bytes) {
+        const size_t at = total;
+        pieces.push_back(Piece{src, bytes, at});
+        total += (bytes + 255) & ~size_t(255);
+        return at;
+    };
+    const size_t o_bases = reserve(b->read_bases, read_bytes), o_qual = reserve(b->read_qual, read_bytes);
+    const size_t o_mapq = reserve(prep ? prep->read_mapq : nullptr, prep ? b->n_reads : 0);
+    const size_t o_roff = reserve(b->read_off, b->n_reads * sizeof(uint32_t)), o_rlen = reserve(b->read_len, b->n_reads * sizeof(uint32_t));
+    const size_t o_hap = reserve(b->hap_bases, hap_bytes);
+    const size_t o_hoff = reserve(b->hap_off, b->n_haps * sizeof(uint32_t)), o_hlen = reserve(b->hap_len, b->n_haps * sizeof(uint32_t));
+    const size_t o_pr = reserve(pr.data(), n_pairs * sizeof(uint32_t)), o_ph = reserve(ph.data(), n_pairs * sizeof(uint32_t));
+    const size_t o_order = reserve(order.data(), n_pairs * sizeof(uint32_t));
+    const size_t o_poff = reserve(plane_off.data(), b->n_haps * sizeof(uint32_t)), o_owner = reserve(owner.data(), slots * sizeof(uint32_t));
+    HIP_TRY(rb->stage.ensure(total));
+    HIP_TRY(rb->blob.alloc(total));
+    for (const Piece &pc : pieces)
+        if (pc.bytes) memcpy(static_cast<uint8_t *>(rb->stage.p) + pc.at, pc.src, pc.bytes);
+    if (total) HIP_TRY(hipMemcpyAsync(rb->blob.p, rb->stage.p, total, hipMemcpyHostToDevice, st));
+    uint8_t *base = rb->blob.p;
+    rb->read_bases = {base + o_bases, (size_t)read_bytes};
+    rb->read_qual = {base + o_qual, (size_t)read_bytes};
+    rb->read_mapq = {base + o_mapq, prep ? (size_t)b->n_reads : 0};
+    rb->read_off = {reinterpret_cast<uint32_t *>(base + o_roff), b->n_reads};
+    rb->read_len = {reinterpret_cast<uint32_t *>(base + o_rlen), b->n_reads};
+    rb->hap_bases = {base + o_hap, (size_t)hap_bytes};
+    rb->hap_off = {reinterpret_cast<uint32_t *>(base + o_hoff), b->n_haps};
+    rb->hap_len = {reinterpret_cast<uint32_t *>(base + o_hlen), b->n_haps};
+    rb->pair_read = {reinterpret_cast<uint32_t *>(base + o_pr), (size_t)n_pairs};
+    rb->pair_hap = {reinterpret_cast<uint32_t *>(base + o_ph), (size_t)n_pairs};
+    rb->order = {reinterpret_cast<uint32_t *>(base + o_order), (size_t)n_pairs};
+    rb->plane_off = {reinterpret_cast<uint32_t *>(base + o_poff), b->n_haps};
+    rb->word_owner = {reinterpret_cast<uint32_t *>(base + o_owner), (size_t)slots};
     rb->del_aliases_ins = prep != nullptr;
     if (prep) {
         HIP_TRY(rb->read_ins.alloc(read_bytes));
         HIP_TRY(rb->read_gcp.alloc(read_bytes));
-        HIP_TRY(rb->read_mapq.upload(prep->read_mapq, b->n_reads, st));
     }
     else {
         HIP_TRY(rb->read_ins.upload(b->read_ins, read_bytes, st));
         HIP_TRY(rb->read_del.upload(b->read_del, read_bytes, st));
         HIP_TRY(rb->read_gcp.upload(b->read_gcp, read_bytes, st));
     }
-    HIP_TRY(rb->read_off.upload(b->read_off, b->n_reads, st));
-    HIP_TRY(rb->read_len.upload(b->read_len, b->n_reads, st));
-    HIP_TRY(rb->hap_bases.upload(b->hap_bases, hap_bytes, st));
-    HIP_TRY(rb->hap_off.upload(b->hap_off, b->n_haps, st));
-    HIP_TRY(rb->hap_len.upload(b->hap_len, b->n_haps, st));
-    HIP_TRY(rb->pair_read.upload(pr.data(), n_pairs, st));
-    HIP_TRY(rb->pair_hap.upload(ph.data(), n_pairs, st));
-    HIP_TRY(rb->order.upload(order.data(), n_pairs, st));
-    HIP_TRY(rb->plane_off.upload(plane_off.data(), b->n_haps, st));
-    HIP_TRY(rb->word_owner.upload(owner.data(), slots, st));
     HIP_TRY(rb->planes.alloc(slots * phmm::kPlanes));
     HIP_TRY(rb->raw32.alloc(n_pairs));
     HIP_TRY(rb->raw64.alloc(n_pairs));
@@ -388,12 +455,10 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
         HIP_TRY(phmm::launch_prep_reads(rb->read_bases.p, rb->read_qual.p, rb->read_ins.p, rb->read_gcp.p, rb->read_off.p,
                                         rb->read_len.p, rb->read_mapq.p, b->n_reads, prep->min_quality_threshold,
                                         prep->pcr_model, prep->gap_open, prep->gap_cont, st));
-    if (n_pairs) {
-        HIP_TRY(hipMemsetAsync(rb->raw64.p, 0, n_pairs * sizeof(double), st));
+    if (n_pairs)
         HIP_TRY(phmm::launch_hap_planes(rb->hap_bases.p, rb->hap_off.p, rb->hap_len.p, rb->plane_off.p, rb->word_owner.p,
                                         (uint32_t)slots, rb->planes.p, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));  // the host vectors above die at return
+    if (!prep) HIP_TRY(hipStreamSynchronize(st));  // read_ins / read_del / read_gcp were copied straight from caller memory
     return PHMM_OK;
 }
 
@@ -533,27 +598,31 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
     if (!c || !rb) return fail(PHMM_E_INVALID, "phmm_download: null argument");
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t n = rb->n_pairs;
-    std::vector<float> raw;
-    float *rp = out_raw_f32;
-    if (!rp && out_log10) {
-        raw.resize(n);
-        rp = raw.data();
-    }
-    if (rp && n) HIP_TRY(hipMemcpyAsync(rp, rb->raw32.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    std::vector<double> r64;
-    if (out_log10 && rb->last_rescued && n) {
-        r64.resize(n);
-        HIP_TRY(hipMemcpyAsync(r64.data(), rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    const bool want = (out_raw_f32 || out_log10) && n;
+    const bool want64 = out_log10 && rb->last_rescued && n;
+    // results come back through pinned staging: [n floats][n doubles when anything was rescued]
+    const size_t off64 = (n * sizeof(float) + 255) & ~size_t(255);
+    if (want) {
+        HIP_TRY(rb->out_stage.ensure(off64 + (want64 ? n * sizeof(double) : 0)));
+        HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (want64)
+            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off64, rb->raw64.p, n * sizeof(double),
+                                   hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (out_log10) {
-        // pairhmm_internal.cpp:577-585 -- libm on the host, as the reference does, so the last ulp agrees
-        for (uint64_t p = 0; p < n; ++p) {
-            const float x = rp[p];
-            if (x < PHMM_MIN_ACCEPTED_F32)
-                out_log10[p] = log10(r64.empty() ? 0.0 : r64[p]) - PHMM_LOG10_INITIAL_CONSTANT_F64;
-            else
-                out_log10[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
+    if (want) {
+        const float *rp = static_cast<const float *>(rb->out_stage.p);
+        const double *r64 = reinterpret_cast<const double *>(static_cast<const uint8_t *>(rb->out_stage.p) + off64);
+        if (out_raw_f32) memcpy(out_raw_f32, rp, n * sizeof(float));
+        if (out_log10) {
+            // pairhmm_internal.cpp:577-585 -- libm on the host, as the reference does, so the last ulp agrees
+            for (uint64_t p = 0; p < n; ++p) {
+                const float x = rp[p];
+                if (x < PHMM_MIN_ACCEPTED_F32)
+                    out_log10[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
+                else
+                    out_log10[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
+            }
         }
     }
     if (stats) {
@@ -591,9 +660,18 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
     phmm_resident *rb = c->scratch;
     int rc = upload_into(c, b, rb);
     if (rc != PHMM_OK) return rc;
-    double ms = 0.0;
-    rc = phmm_sweep_timed(c, rb, 1, &ms, nullptr);
-    if (rc == PHMM_OK) rc = phmm_download(c, rb, out_raw_f32, out_log10, stats);
+    // one pass; the events are read only after the download's synchronisation (no extra round trip for the timing)
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    rc = phmm_sweep(c, rb);
+    if (rc != PHMM_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    rc = phmm_download(c, rb, out_raw_f32, out_log10, nullptr);
+    if (rc == PHMM_OK && stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        rb->last_kernel_ms = ms;
+        rc = phmm_download(c, rb, nullptr, nullptr, stats);
+    }
     if (rc == PHMM_OK && stats)
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
