@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -120,6 +121,11 @@ struct phmm_context
     DevBuf<float> ph2pr_f32, mm_f32;
     DevBuf<double> ph2pr_f64, mm_f64;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the per-K launches of one pass are independent: they are spread over a few side streams so that the tail of one
+    // launch overlaps the head of the next (mixed-length batches have up to 17 launches per pass)
+    static constexpr int kSideStreams = 3;
+    hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
     struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
 };
 
@@ -139,6 +145,10 @@ static int pick_waves_per_team(uint32_t n_pairs, uint32_t max_read, uint32_t max
     const uint32_t quads = (n_pairs + 3) / 4;
     const uint32_t stripes = (max_read + stripe_rows - 1) / stripe_rows;
     const uint32_t supersteps = (max_hap + 15 + 31) / 32;
+    if (const char *f = getenv("PHMM_FORCE_TEAM_WAVES")) {  // tests: exercise every team width on small batches
+        const int w = atoi(f);
+        if ((w == 1 || w == 4 || w == 8) && supersteps >= 4u * w + 12u) return w;
+    }
     if (quads < 2048 && stripes >= 8 && supersteps >= 4 * 8 + 12) return 8;
     if (quads < 4096 && stripes >= 4 && supersteps >= 4 * 4 + 12) return 4;
     return 1;
@@ -227,6 +237,11 @@ int phmm_create(int device_id, void *stream, phmm_context **out)
     if (e == hipSuccess) e = c->mm_f64.upload(t.mm_f64.data(), phmm::kMmTableSize, c->stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+    for (int i = 0; i < phmm_context::kSideStreams && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         phmm_destroy(c);
@@ -243,6 +258,12 @@ void phmm_destroy(phmm_context *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+        if (c->side[i]) (void)hipStreamSynchronize(c->side[i]);
+        if (c->join[i]) (void)hipEventDestroy(c->join[i]);
+        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+    }
     delete c->scratch;
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -337,10 +358,10 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
         if (K > (uint32_t)phmm::kMaxRowsPerLane || H > kSinglePassMaxHap) {
             const uint32_t S = phmm::kLanesPerPair * phmm::kStripedRowsF32;
             const uint64_t stripes = std::min<uint64_t>((R + S - 1) / S, 63u);
-            keys[p] = (17ull << 58) | (stripes << 52) | ((uint64_t)H << 32) | p;  // H < 2^20
+            keys[p] = (17ull << 58) | (stripes << 52) | ((uint64_t)(0xFFFFFu - H) << 32) | p;  // longest haplotypes first
         }
         else {
-            keys[p] = ((uint64_t)K << 58) | ((uint64_t)H << 32) | p;
+            keys[p] = ((uint64_t)K << 58) | ((uint64_t)(0xFFFFFu - H) << 32) | p;  // H < 2^20; longest first: short tail
         }
     }
     std::sort(keys.begin(), keys.end());
@@ -479,7 +500,15 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
 
 static int sweep_fp32(phmm_context *c, phmm_resident *rb)
 {
+    const bool fan_out = rb->bins.size() > 1;
+    if (fan_out) {
+        HIP_TRY(hipEventRecord(c->fork, c->stream));
+        for (int i = 0; i < phmm_context::kSideStreams; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
+    }
+    int nth = 0;
     for (const Bin &bin : rb->bins) {
+        const int lane = fan_out ? nth++ % (phmm_context::kSideStreams + 1) : 0;
+        hipStream_t stream = lane == 0 ? c->stream : c->side[lane - 1];
         phmm::KernelArgs a{};
         a.read_bases = rb->read_bases.p;
         a.read_qual = rb->read_qual.p;
@@ -500,7 +529,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.mm_table = c->mm_f32.p;
         a.out_raw = rb->raw32.p;
         if (bin.rows_per_lane > 0) {
-            HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, c->stream));
+            HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, stream));
         }
         else {
             const int wp = pick_waves_per_team(bin.count, bin.max_read_len, bin.max_hap_len,
@@ -509,7 +538,13 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
             const uint32_t stride = bin.max_hap_len + 1;
             const size_t need = phmm::team_carry_values(teams, wp, stride);
             HIP_TRY(rb->carry32.alloc(need));
-            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, wp, a, rb->carry32.p, stride, teams, c->stream));
+            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, wp, a, rb->carry32.p, stride, teams, stream));
+        }
+    }
+    if (fan_out) {
+        for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+            HIP_TRY(hipEventRecord(c->join[i], c->side[i]));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->join[i], 0));
         }
     }
     return PHMM_OK;
