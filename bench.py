@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="multiplies the number of regions of the config")
     ap.add_argument("--chunk-regions", type=int, default=1000, help="regions per resident chunk (c4 streams 12.5 chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(cores, 16))")
     args = ap.parse_args()
 
     import numpy as np
@@ -191,7 +191,8 @@ def cpu_baseline(batch, gpu_raw, gpu_l10, threads):
         n_cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    threads = threads or n_cores
+    # the box's CPU share for one GPU is 16 cores: more threads than that only measures oversubscription
+    threads = threads or min(n_cores, 16)
     cells = batch.cells()
     if oracle.ref() is not None:
         raw, sec = oracle.ref_regions_16x1(batch, n_threads=threads)

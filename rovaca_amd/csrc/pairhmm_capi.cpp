@@ -157,6 +157,7 @@ static int pick_waves_per_team(uint32_t n_pairs, uint32_t max_read, uint32_t max
 // single-pass kernels keep 16 pairs' haplotype planes in LDS per workgroup; longer haplotypes take the striped kernel
 constexpr uint32_t kSinglePassMaxHap = 4096;
 constexpr uint32_t kMaxLen = 1u << 20;
+constexpr uint32_t kRescueMaxTeams = 4096;    // workgroups of the fp64 re-run (they stride over the rescue queue)
 constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
 
 struct phmm_resident
@@ -500,6 +501,7 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
 
 static int sweep_fp32(phmm_context *c, phmm_resident *rb)
 {
+    if (rb->n_pairs) HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, sizeof(uint32_t), c->stream));
     const bool fan_out = rb->bins.size() > 1;
     if (fan_out) {
         HIP_TRY(hipEventRecord(c->fork, c->stream));
@@ -528,6 +530,8 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.ph2pr = c->ph2pr_f32.p;
         a.mm_table = c->mm_f32.p;
         a.out_raw = rb->raw32.p;
+        a.rescue_list = rb->rescue_list.p;
+        a.rescue_count = rb->rescue_count.p;
         if (bin.rows_per_lane > 0) {
             HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, stream));
         }
@@ -552,19 +556,13 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
 
 static int sweep_rescue(phmm_context *c, phmm_resident *rb)
 {
+    // The fp64 re-run of the pairs the fp32 kernels queued.  Nothing comes back to the host between the two passes: the
+    // team kernel reads the queue length from device memory and its workgroups stride over the queue (all of them leave
+    // at once when it is empty), so a pass is one asynchronous chain on the context's stream.
     if (rb->n_pairs == 0) return PHMM_OK;
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, sizeof(uint32_t), st));
-    HIP_TRY(phmm::launch_collect_rescue(rb->raw32.p, (uint32_t)rb->n_pairs, rb->rescue_list.p, rb->rescue_count.p,
-                                        (uint32_t)rb->n_pairs, st));
-    uint32_t n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, rb->rescue_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    rb->last_rescued = n;
-    if (n == 0) return PHMM_OK;
-    // the fp64 re-run: the striped systolic kernel in double, over the queue, results to raw64[pair]
-    const int wp = pick_waves_per_team(n, rb->max_read_len, rb->max_hap_len, phmm::kLanesPerPair * phmm::kStripedRowsF64);
-    const uint32_t teams = std::min<uint32_t>((n + 3) / 4, kStripedMaxTeams / wp);
+    const int wp = pick_waves_per_team(UINT32_MAX, rb->max_read_len, rb->max_hap_len, phmm::kLanesPerPair * phmm::kStripedRowsF64);
+    const uint32_t teams = std::min<uint32_t>((uint32_t)((rb->n_pairs + 3) / 4), kRescueMaxTeams / wp);
     const uint32_t stride = rb->max_hap_len + 1;
     const size_t need = phmm::team_carry_values(teams, wp, stride);
     HIP_TRY(rb->carry64.alloc(need));
@@ -582,7 +580,8 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     a.pair_read = rb->pair_read.p;
     a.pair_hap = rb->pair_hap.p;
     a.order = rb->rescue_list.p;
-    a.n_pairs = n;
+    a.n_pairs = 0;
+    a.n_pairs_dev = rb->rescue_count.p;
     a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(rb->max_hap_len);
     a.ph2pr = c->ph2pr_f64.p;
     a.mm_table = c->mm_f64.p;
@@ -634,17 +633,23 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t n = rb->n_pairs;
     const bool want = (out_raw_f32 || out_log10) && n;
-    const bool want64 = out_log10 && rb->last_rescued && n;
-    // results come back through pinned staging: [n floats][n doubles when anything was rescued]
-    const size_t off64 = (n * sizeof(float) + 255) & ~size_t(255);
-    if (want) {
-        HIP_TRY(rb->out_stage.ensure(off64 + (want64 ? n * sizeof(double) : 0)));
-        HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        if (want64)
-            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off64, rb->raw64.p, n * sizeof(double),
-                                   hipMemcpyDeviceToHost, c->stream));
+    // results come back through pinned staging: [n floats][rescue count][n doubles when anything was rescued]
+    const size_t off_cnt = (n * sizeof(float) + 255) & ~size_t(255);
+    const size_t off64 = off_cnt + 256;
+    if (n) {
+        HIP_TRY(rb->out_stage.ensure(off64 + n * sizeof(double)));
+        if (want) HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off_cnt, rb->rescue_count.p, sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) rb->last_rescued = *reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(rb->out_stage.p) + off_cnt);
+    const bool want64 = out_log10 && rb->last_rescued && n;
+    if (want64) {
+        HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off64, rb->raw64.p, n * sizeof(double),
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     if (want) {
         const float *rp = static_cast<const float *>(rb->out_stage.p);
         const double *r64 = reinterpret_cast<const double *>(static_cast<const uint8_t *>(rb->out_stage.p) + off64);

@@ -37,6 +37,11 @@ struct KernelArgs
     const void *ph2pr;
     const void *mm_table;
     void *out_raw;  // [n_pairs of the whole batch], indexed by pair id
+    // fp32 launches: pairs whose sum fell below 1e-28f (rovaca/common.h:9) are appended here for the fp64 re-run
+    uint32_t *rescue_list;
+    uint32_t *rescue_count;
+    // fp64 re-run: the number of pairs in `order` is read from device memory (no host round trip between the passes)
+    const uint32_t *n_pairs_dev;
 };
 
 hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const KernelArgs &a, hipStream_t s);
@@ -60,8 +65,6 @@ hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, 
 hipError_t launch_prep_reads(const uint8_t *read_bases, uint8_t *read_qual, uint8_t *read_gop, uint8_t *read_gcp,
                              const uint32_t *read_off, const uint32_t *read_len, const uint8_t *read_mapq, uint32_t n_reads,
                              int32_t min_q, int32_t pcr_model, uint8_t gap_open, uint8_t gap_cont, hipStream_t s);
-hipError_t launch_collect_rescue(const float *raw, uint32_t n_pairs, uint32_t *list, uint32_t *count, uint32_t capacity,
-                                 hipStream_t s);
 
 }  // namespace phmm
 #endif

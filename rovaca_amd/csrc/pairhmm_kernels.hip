@@ -320,7 +320,12 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_
         if ((t & 31u) == 1u) reload(t);
         if (t <= Tg) step_t(t);
     }
-    if (valid && lane == kLanesPerPair - 1) reinterpret_cast<T *>(a.out_raw)[pair] = sumM + sumX;
+    if (valid && lane == kLanesPerPair - 1) {
+        const T res = sumM + sumX;
+        reinterpret_cast<T *>(a.out_raw)[pair] = res;
+        if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))  // pairhmm_internal.cpp:578: queue for fp64
+            a.rescue_list[atomicAdd(a.rescue_count, 1u)] = pair;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -365,11 +370,12 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
     const T *rM = carry + ((static_cast<size_t>(team) * WP + prev_wave) * 4u + grp) * 3u * carry_stride;
     const T *rX = rM + carry_stride, *rY = rX + carry_stride;
 
-    const uint32_t quads = (a.n_pairs + 3u) / 4u;
+    const uint32_t n_pairs = a.n_pairs_dev ? *a.n_pairs_dev : a.n_pairs;  // uniform over the grid
+    const uint32_t quads = (n_pairs + 3u) / 4u;
     const uint32_t iters = (quads + n_teams - 1) / n_teams;
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t gidx = (it * n_teams + team) * 4u + grp;
-        const bool valid = gidx < a.n_pairs;
+        const bool valid = gidx < n_pairs;
         const uint32_t pair = a.order[valid ? gidx : 0];
         const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
         const uint32_t R = a.read_len[r], H = a.hap_len[h];
@@ -623,8 +629,12 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                         }
                         ring_fetch(t + 1);
                     }
-                    if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == kLanesPerPair - 1)
-                        reinterpret_cast<T *>(a.out_raw)[pair] = sumM + sumX;
+                    if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == kLanesPerPair - 1) {
+                        const T res = sumM + sumX;
+                        reinterpret_cast<T *>(a.out_raw)[pair] = res;
+                        if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))
+                            a.rescue_list[atomicAdd(a.rescue_count, 1u)] = pair;
+                    }
                 }
             }
             __syncthreads();  // carry columns written in this superstep are visible to the team before the next one
@@ -715,18 +725,6 @@ __global__ void prep_reads_kernel(const uint8_t *__restrict__ read_bases, uint8_
     }
 }
 
-// fp32 results below the acceptance threshold (rovaca/common.h:9, MIN_ACCEPTED 1e-28f) are queued for fp64
-__global__ void collect_rescue_kernel(const float *__restrict__ raw, uint32_t n_pairs, uint32_t *__restrict__ list,
-                                      uint32_t *__restrict__ count, uint32_t capacity)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    if (raw[p] < 1e-28f) {
-        const uint32_t at = atomicAdd(count, 1u);
-        if (at < capacity) list[at] = p;
-    }
-}
-
 // ----------------------------------------------------------------------------------------------------
 // launchers (one instantiation per rows-per-lane K)
 // ----------------------------------------------------------------------------------------------------
@@ -774,7 +772,7 @@ template <typename T, int K>
 static hipError_t launch_team_t(bool ug, int waves_per_team, const KernelArgs &a, void *carry, uint32_t carry_stride,
                                 uint32_t teams, hipStream_t s)
 {
-    if (a.n_pairs == 0) return hipSuccess;
+    if (a.n_pairs == 0 && !a.n_pairs_dev) return hipSuccess;
     if (waves_per_team == 8)
         return ug ? launch_team_one<T, K, true, 8>(a, carry, carry_stride, teams, s)
                   : launch_team_one<T, K, false, 8>(a, carry, carry_stride, teams, s);
@@ -816,15 +814,6 @@ hipError_t launch_prep_reads(const uint8_t *read_bases, uint8_t *read_qual, uint
     if (n_reads == 0) return hipSuccess;
     hipLaunchKernelGGL(prep_reads_kernel, dim3(n_reads), dim3(128), 0, s, read_bases, read_qual, read_gop, read_gcp, read_off,
                        read_len, read_mapq, min_q, pcr_model, gap_open, gap_cont);
-    return hipGetLastError();
-}
-
-hipError_t launch_collect_rescue(const float *raw, uint32_t n_pairs, uint32_t *list, uint32_t *count, uint32_t capacity,
-                                 hipStream_t s)
-{
-    if (n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(collect_rescue_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, raw, n_pairs, list, count,
-                       capacity);
     return hipGetLastError();
 }
 
