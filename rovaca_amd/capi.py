@@ -42,12 +42,9 @@ class PhmmError(RuntimeError):
     pass
 
 
-def build(force=False):
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True)
-    else:
-        subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True)  # no-op when up to date
+def build():
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU); a no-op when up to date."""
+    subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True)
     return LIB_PATH
 
 

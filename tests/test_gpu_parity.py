@@ -268,3 +268,20 @@ def test_team_kernel_every_width(engine, waves, monkeypatch):
         pairs.append((len(reads) - 1, len(haps) - 1))
     pairs += [(0, 1), (2, 0), (4, 6)]
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
+
+
+def test_symbols_outside_ACGTN_never_match(engine):
+    # pairhmm_internal.cpp:27-41: lower case, IUPAC codes, '-' ... map to code 0 and match nothing, not even themselves
+    rng = np.random.default_rng(31)
+    b = synth.make_batch(seed=31, n_regions=2, reads=12, haps=4, read_len=(30, 180), hap_len=(200, 320), n_rate=0.01,
+                         hap_n_rate=0.01)
+    odd = np.frombuffer(b"acgtnRYKM-*.", np.uint8)
+    rb = b.read_bases.copy()
+    hb = b.hap_bases.copy()
+    rb[rng.random(rb.shape[0]) < 0.03] = rng.choice(odd, int((rng.random(rb.shape[0]) < 0.03).sum()) or 1)[0]
+    idx = np.nonzero(rng.random(rb.shape[0]) < 0.03)[0]
+    rb[idx] = rng.choice(odd, idx.size)
+    idx = np.nonzero(rng.random(hb.shape[0]) < 0.02)[0]
+    hb[idx] = rng.choice(odd, idx.size)
+    b.read_bases, b.hap_bases = rb, hb
+    _check_against_oracle(engine, b)
