@@ -137,21 +137,36 @@ struct Bin
     uint32_t max_hap_len, max_read_len;
 };
 
-// How many waves cooperate on one quad of pairs in the striped kernel: enough stripes to keep them busy, a haplotype long
-// enough for the pipeline lag (kLag = 4 supersteps of 32 columns per wave), and only when the batch is too small to fill the
-// chip with one wave per quad.
-static int pick_waves_per_team(uint32_t n_pairs, uint32_t max_read, uint32_t max_hap, uint32_t stripe_rows)
+// Geometry of a striped launch.  lanes: 16 puts four pairs in a wave, 64 gives a whole wave to one pair (chosen when the
+// launch has so few pairs that four-per-wave would leave most of the chip idle and the reads are long enough to fill 64-lane
+// stripes).  waves: how many waves pipeline the stripes of the same pairs -- enough stripes to keep them busy, a haplotype
+// long enough for the pipeline lag (4 or 6 supersteps of 32 columns per wave), and only when the batch is small.
+struct TeamShape
 {
-    const uint32_t quads = (n_pairs + 3) / 4;
-    const uint32_t stripes = (max_read + stripe_rows - 1) / stripe_rows;
-    const uint32_t supersteps = (max_hap + 15 + 31) / 32;
+    int lanes, waves;
+};
+static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t max_hap, uint32_t rows_per_lane)
+{
+    TeamShape sh{16, 1};
+    if ((n_pairs + 3) / 4 < 1024 && max_read > 64u * rows_per_lane) sh.lanes = 64;
+    if (const char *f = getenv("PHMM_FORCE_TEAM_LANES")) {  // tests
+        const int l = atoi(f);
+        if (l == 16 || l == 64) sh.lanes = l;
+    }
+    const uint32_t per_wave = 64u / (uint32_t)sh.lanes;
+    const uint32_t batches = (n_pairs + per_wave - 1) / per_wave;
+    const uint32_t stripes = (max_read + sh.lanes * rows_per_lane - 1) / (sh.lanes * rows_per_lane);
+    const uint32_t supersteps = (max_hap + (uint32_t)sh.lanes - 1 + 31) / 32;
+    const uint32_t lag = sh.lanes == 64 ? 6u : 4u;  // team_lag<G>() of the kernel
+    if (sh.lanes == 16 && batches < 2048 && stripes >= 8 && supersteps >= lag * 8 + 12)
+        sh.waves = 8;
+    else if (batches < 4096 && stripes >= 4 && supersteps >= lag * 4 + 12)
+        sh.waves = 4;
     if (const char *f = getenv("PHMM_FORCE_TEAM_WAVES")) {  // tests: exercise every team width on small batches
         const int w = atoi(f);
-        if ((w == 1 || w == 4 || w == 8) && supersteps >= 4u * w + 12u) return w;
+        if ((w == 1 || w == 4 || w == 8) && supersteps >= lag * w + 12u) sh.waves = w;
     }
-    if (quads < 2048 && stripes >= 8 && supersteps >= 4 * 8 + 12) return 8;
-    if (quads < 4096 && stripes >= 4 && supersteps >= 4 * 4 + 12) return 4;
-    return 1;
+    return sh;
 }
 
 // single-pass kernels keep 16 pairs' haplotype planes in LDS per workgroup; longer haplotypes take the striped kernel
@@ -319,7 +334,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     }
     if (max_read > kMaxLen || max_hap > kMaxLen)
         return fail(PHMM_E_INVALID, "phmm_upload: sequence longer than %u bases", kMaxLen);
-    if (phmm::team_lds_bytes((uint32_t)phmm::kPlanes * phmm::planes_words(max_hap), 8, 8) > 160u * 1024u)
+    if (phmm::team_lds_bytes((uint32_t)phmm::kPlanes * phmm::planes_words(max_hap), 8, 8, 16) > 160u * 1024u)
         return fail(PHMM_E_INVALID, "phmm_upload: haplotype of %u bases exceeds the LDS plane budget", max_hap);
 
     rb->bins.clear();
@@ -536,13 +551,12 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
             HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, stream));
         }
         else {
-            const int wp = pick_waves_per_team(bin.count, bin.max_read_len, bin.max_hap_len,
-                                               phmm::kLanesPerPair * phmm::kStripedRowsF32);
-            const uint32_t teams = std::min<uint32_t>((bin.count + 3) / 4, kStripedMaxTeams / wp);
+            const TeamShape sh = pick_team_shape(bin.count, bin.max_read_len, bin.max_hap_len, phmm::kStripedRowsF32);
+            const uint32_t per_wave = 64u / (uint32_t)sh.lanes;
+            const uint32_t teams = std::min<uint32_t>((bin.count + per_wave - 1) / per_wave, kStripedMaxTeams / sh.waves);
             const uint32_t stride = bin.max_hap_len + 1;
-            const size_t need = phmm::team_carry_values(teams, wp, stride);
-            HIP_TRY(rb->carry32.alloc(need));
-            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, wp, a, rb->carry32.p, stride, teams, stream));
+            HIP_TRY(rb->carry32.alloc(phmm::team_carry_values(teams, sh.waves, stride, sh.lanes)));
+            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, sh.waves, sh.lanes, a, rb->carry32.p, stride, teams, stream));
         }
     }
     if (fan_out) {
@@ -561,11 +575,13 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     // at once when it is empty), so a pass is one asynchronous chain on the context's stream.
     if (rb->n_pairs == 0) return PHMM_OK;
     hipStream_t st = c->stream;
-    const int wp = pick_waves_per_team(UINT32_MAX, rb->max_read_len, rb->max_hap_len, phmm::kLanesPerPair * phmm::kStripedRowsF64);
-    const uint32_t teams = std::min<uint32_t>((uint32_t)((rb->n_pairs + 3) / 4), kRescueMaxTeams / wp);
+    // the queue length is not known on the host: shape the launch for the whole batch (few pairs -> one pair per wave)
+    const TeamShape sh = pick_team_shape((uint32_t)std::min<uint64_t>(rb->n_pairs, 0xFFFFFFFFull), rb->max_read_len,
+                                         rb->max_hap_len, phmm::kStripedRowsF64);
+    const uint32_t per_wave = 64u / (uint32_t)sh.lanes;
+    const uint32_t teams = std::min<uint32_t>((uint32_t)((rb->n_pairs + per_wave - 1) / per_wave), kRescueMaxTeams / sh.waves);
     const uint32_t stride = rb->max_hap_len + 1;
-    const size_t need = phmm::team_carry_values(teams, wp, stride);
-    HIP_TRY(rb->carry64.alloc(need));
+    HIP_TRY(rb->carry64.alloc(phmm::team_carry_values(teams, sh.waves, stride, sh.lanes)));
     phmm::KernelArgs a{};
     a.read_bases = rb->read_bases.p;
     a.read_qual = rb->read_qual.p;
@@ -586,7 +602,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     a.ph2pr = c->ph2pr_f64.p;
     a.mm_table = c->mm_f64.p;
     a.out_raw = rb->raw64.p;
-    HIP_TRY(phmm::launch_striped_f64(rb->uniform_gcp, wp, a, rb->carry64.p, stride, teams, st));
+    HIP_TRY(phmm::launch_striped_f64(rb->uniform_gcp, sh.waves, sh.lanes, a, rb->carry64.p, stride, teams, st));
     return PHMM_OK;
 }
 

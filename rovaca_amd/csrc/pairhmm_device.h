@@ -47,17 +47,19 @@ struct KernelArgs
 hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const KernelArgs &a, hipStream_t s);
 // striped ("team") kernels: a workgroup of waves_per_team waves (1, 4 or 8) sweeps four pairs; lds_words_per_group is
 // kPlanes * planes_words(longest haplotype of the launch); carry holds 3 * carry_stride values per (team, wave, group).
-hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, const KernelArgs &a, float *carry, uint32_t carry_stride,
-                              uint32_t teams, hipStream_t s);
-hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, const KernelArgs &a, double *carry, uint32_t carry_stride,
-                              uint32_t teams, hipStream_t s);
-inline size_t team_lds_bytes(uint32_t plane_words_per_group, int waves_per_team, size_t value_bytes)
+// lanes_per_pair: 16 (four pairs per wave) or 64 (one pair per wave)
+hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, float *carry,
+                              uint32_t carry_stride, uint32_t teams, hipStream_t s);
+hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, double *carry,
+                              uint32_t carry_stride, uint32_t teams, hipStream_t s);
+inline size_t team_lds_bytes(uint32_t plane_words_per_group, int waves_per_team, size_t value_bytes, int lanes_per_pair)
 {
-    return 4u * (size_t)plane_words_per_group * sizeof(uint32_t) + (size_t)waves_per_team * 4u * 3u * 64u * value_bytes;
+    const size_t groups = 64u / (size_t)lanes_per_pair;
+    return groups * (size_t)plane_words_per_group * sizeof(uint32_t) + (size_t)waves_per_team * groups * 3u * 64u * value_bytes;
 }
-inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t carry_stride)
+inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t carry_stride, int lanes_per_pair)
 {
-    return (size_t)teams * waves_per_team * 4u * 3u * carry_stride;
+    return (size_t)teams * waves_per_team * (64u / (size_t)lanes_per_pair) * 3u * carry_stride;
 }
 hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
                              const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,

@@ -50,6 +50,31 @@ __device__ __forceinline__ double dpp_row_shr1(double old, double src)
     return r.d;
 }
 
+__device__ __forceinline__ float dpp_wave_shr1(float old, float src)
+{
+    // lane i of the wave receives lane i-1 (crossing the 16-lane rows); lane 0 keeps `old`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x138, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ double dpp_wave_shr1(double old, double src)
+{
+    union { double d; int i[2]; } o, s, r;
+    o.d = old;
+    s.d = src;
+    r.i[0] = __builtin_amdgcn_update_dpp(o.i[0], s.i[0], 0x138, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], s.i[1], 0x138, 0xF, 0xF, false);
+    return r.d;
+}
+
+template <int G, typename T>
+__device__ __forceinline__ T dpp_shr1(T old, T src)
+{
+    if constexpr (G == 64)
+        return dpp_wave_shr1(old, src);
+    else
+        return dpp_row_shr1(old, src);
+}
+
 // read symbol -> plane class: A C G T N other  (one-hot semantics of pairhmm_internal.cpp:27-41)
 __device__ __forceinline__ uint32_t read_class(uint8_t b)
 {
@@ -128,10 +153,10 @@ struct Rows
 // Occupancy target (waves per SIMD) handed to the register allocator, from measurements per K (tools/bench_by_k.py): the UG
 // kernel at K = 10 (150-bp reads) needs 131 VGPRs unconstrained, 3 more than the 128 that admit a fourth wave; K = 11 still
 // wins at 4 waves with a few spills outside the steady loop; K = 12..14 run best at 3 waves.
-#define PHMM_MIN_WAVES(K, UG) (((UG) && (K) <= 11) ? 4 : ((UG) && (K) <= 14) ? 3 : 1)
+#define PHMM_MIN_WAVES(T, K, UG) (sizeof(T) == 8 ? 2 : ((UG) && (K) <= 11) ? 4 : ((UG) && (K) <= 14) ? 3 : 1)
 
 template <typename T, int K, bool UG>
-__global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_systolic_kernel(KernelArgs a)
+__global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(T, K, UG)) pairhmm_systolic_kernel(KernelArgs a)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & 15u;                                    // lane inside the pair's 16-lane array
@@ -345,36 +370,41 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(K, UG)) pairhmm_
 // that need them.  WP = 1 is the plain striped sweep (no pipeline, the barrier is trivial).  This is what fills the chip
 // when a batch has few, long pairs (BASELINE config 5), and it is how the fp64 re-run is done.
 // ----------------------------------------------------------------------------------------------------
-constexpr uint32_t kLag = 4;  // supersteps between consecutive stripes of a pair: the consumer reads two blocks ahead
+// supersteps between consecutive stripes of a pair.  The consumer reads three blocks (96 columns) ahead of its first step and
+// the producer's last lane trails its first by G - 1 columns, so 32 * lag >= 95 + G: 4 for 16-lane arrays, 5 (we take 6) for 64.
+template <int G> constexpr uint32_t team_lag() { return G == 64 ? 6u : 4u; }
 
-template <typename T, int K, bool UG, int WP>
+// G = lanes per pair: 16 (four pairs per wave, DPP row_shr) or 64 (one pair per wave, DPP wave_shr -- for batches with
+// so few pairs that four-per-wave would leave the chip empty: one long-read pair then keeps up to WP waves busy)
+template <typename T, int K, bool UG, int WP, int G>
 __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
 {
     extern __shared__ uint32_t lds[];
-    constexpr int S = kLanesPerPair * K;
-    constexpr uint32_t kRing = 64;  // columns parked per value: two blocks of 32
-    const uint32_t lane = threadIdx.x & 15u;
-    const uint32_t grp = (threadIdx.x >> 4) & 3u;
+    constexpr int S = G * K;
+    constexpr uint32_t kGroups = 64 / G;  // pairs per wave
+    constexpr uint32_t kRing = 64;        // columns parked per value: two blocks of 32
+    constexpr uint32_t kLag = team_lag<G>();
+    const uint32_t lane = threadIdx.x & (G - 1);
+    const uint32_t grp = (threadIdx.x & 63u) / G;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t team = blockIdx.x, n_teams = gridDim.x;
     const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
     const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
-    // LDS: [4 groups][planes] shared by the team, then [WP waves][4 groups][3 values][kRing] carry ring
+    // LDS: [kGroups][planes] shared by the team, then [WP waves][kGroups][3 values][kRing] carry ring
     const uint32_t plane_words = a.lds_words_per_group;
     uint32_t *pl = lds + grp * plane_words;
-    T *ring = reinterpret_cast<T *>(lds + 4u * plane_words) + (static_cast<size_t>(wave) * 4u + grp) * 3u * kRing;
-    // carry rows: one per (team, wave, group); stripe v reads the row of the wave that ran stripe v - 1
-    const uint32_t prev_wave = (wave + WP - 1) % WP;
-    T *wM = carry + ((static_cast<size_t>(team) * WP + wave) * 4u + grp) * 3u * carry_stride;
-    T *wX = wM + carry_stride, *wY = wX + carry_stride;
-    const T *rM = carry + ((static_cast<size_t>(team) * WP + prev_wave) * 4u + grp) * 3u * carry_stride;
-    const T *rX = rM + carry_stride, *rY = rX + carry_stride;
-
+    T *ring = reinterpret_cast<T *>(lds + kGroups * plane_words) + (static_cast<size_t>(wave) * kGroups + grp) * 3u * kRing;
+    // carry rows: one slab per (team, wave), laid out [column][group][M, X, Y] so that the slab base is wave-uniform (an
+    // SGPR pair) and lane 15 writes its three values with one store; stripe v reads the slab of the wave that ran v - 1
+    const uint32_t uwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    const uint32_t prev_wave = (uwave + WP - 1) % WP;
+    T *wbase = carry + (static_cast<size_t>(team) * WP + uwave) * 3u * kGroups * carry_stride;
+    const T *rbase = carry + (static_cast<size_t>(team) * WP + prev_wave) * 3u * kGroups * carry_stride;
     const uint32_t n_pairs = a.n_pairs_dev ? *a.n_pairs_dev : a.n_pairs;  // uniform over the grid
-    const uint32_t quads = (n_pairs + 3u) / 4u;
+    const uint32_t quads = (n_pairs + kGroups - 1) / kGroups;  // pairs are taken kGroups at a time
     const uint32_t iters = (quads + n_teams - 1) / n_teams;
     for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t gidx = (it * n_teams + team) * 4u + grp;
+        const uint32_t gidx = (it * n_teams + team) * kGroups + grp;
         const bool valid = gidx < n_pairs;
         const uint32_t pair = a.order[valid ? gidx : 0];
         const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
@@ -384,23 +414,27 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
         __syncthreads();  // the previous quad's planes are no longer read
         {
             const uint32_t *src = a.planes + a.plane_off[h];
-            for (uint32_t i = lane + kLanesPerPair * wave; i < kPlanes * W; i += kLanesPerPair * WP) pl[i] = src[i];
+            for (uint32_t i = lane + G * wave; i < kPlanes * W; i += G * WP) pl[i] = src[i];
         }
         const T init_y = Num<T>::init_const() / static_cast<T>(H);
         const uint32_t n_stripes = valid ? (R + S - 1) / S : 0;
         const int pad = static_cast<int>(n_stripes) * S - static_cast<int>(R);
         uint32_t max_stripes = n_stripes;  // team-uniform; a pair with fewer stripes joins late so that all end together
-        max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 16));
-        max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 32));
+        if (kGroups > 1) {
+            max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 16));
+            max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 32));
+        }
         max_stripes = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_stripes);
-        const uint32_t Tpair = valid ? H + (kLanesPerPair - 1) : 0;
+        const uint32_t Tpair = valid ? H + (G - 1) : 0;
         uint32_t Tmax = Tpair;
-        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
-        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+        if (kGroups > 1) {
+            Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+            Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+        }
         Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
         const uint32_t Bs = (Tmax + 31u) / 32u;                // supersteps per stripe
         const uint32_t n_rounds = (max_stripes + WP - 1) / WP;  // stripes per wave
-        const uint32_t G = n_rounds * Bs + kLag * (WP - 1);     // supersteps of this quad
+        const uint32_t n_super = n_rounds * Bs + kLag * (WP - 1);  // supersteps of this batch of pairs
         const uint32_t wmax = W - 2;
         __syncthreads();  // planes staged
 
@@ -446,7 +480,7 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
         auto carry_load = [&](uint32_t blk) {  // columns 32 * blk + 1 + lane (+ 16) of the producer's row
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                uint32_t j = 32u * blk + 1u + lane + 16u * q;
+                uint32_t j = 32u * blk + 1u + (lane & 15u) + 16u * q;  // G = 64: lanes 16..63 repeat lanes 0..15
                 j = j <= H ? j : H;
                 if (first) {
                     preM[q] = 0;
@@ -454,14 +488,15 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                     preY[q] = init_y;
                 }
                 else {
-                    preM[q] = __hip_atomic_load(rM + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    preX[q] = __hip_atomic_load(rX + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    preY[q] = __hip_atomic_load(rY + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const T *src = rbase + (j * kGroups + grp) * 3u;
+                    preM[q] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    preX[q] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    preY[q] = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         };
         auto carry_park = [&](uint32_t blk) {
-            const uint32_t base = (blk & 1u) * 32u + lane;
+            const uint32_t base = (blk & 1u) * 32u + (lane & 15u);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 ring[base + 16 * q] = preM[q];
@@ -469,11 +504,12 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                 ring[2 * kRing + base + 16 * q] = preY[q];
             }
         };
-        auto ring_fetch = [&](uint32_t t) {  // column t
+        T nxtM = 0, nxtX = 0, nxtY = 0;
+        auto ring_fetch = [&](uint32_t t) {  // column t -> the "next" registers (issued a whole step before they are used)
             const uint32_t e = (t - 1) & (kRing - 1);
-            curM = ring[e];
-            curX = ring[kRing + e];
-            curY = ring[2 * kRing + e];
+            nxtM = ring[e];
+            nxtX = ring[kRing + e];
+            nxtY = ring[2 * kRing + e];
         };
         auto masks_reload = [&](uint32_t t) {
             const uint32_t jn = t > lane ? t - lane : 1u;
@@ -566,12 +602,15 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
             carry_park(1);
             carry_load(2);
             ring_fetch(1);
+            curM = nxtM;
+            curX = nxtX;
+            curY = nxtY;
         };
         auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
             // lane 0 keeps `old` = the row above at column t (boundary row or carry); lanes 1..15 take lane-1's last row
-            uM0 = dpp_row_shr1(curM, M[K - 1]);
-            uX0 = dpp_row_shr1(curX, X[K - 1]);
-            uY0 = dpp_row_shr1(curY, Y[K - 1]);
+            uM0 = dpp_shr1<G>(curM, M[K - 1]);
+            uX0 = dpp_shr1<G>(curX, X[K - 1]);
+            uY0 = dpp_shr1<G>(curY, Y[K - 1]);
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
                 uint32_t nm;
@@ -584,6 +623,7 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                 tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
                 tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
                 M[k] = tt * prior;
+                __builtin_amdgcn_sched_barrier(0);  // rows in program order, as in the single-pass kernel
             }
             T uM = uM0, uX = uX0;
 #pragma unroll
@@ -596,15 +636,17 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                 sumM = sumM + M[K - 1];
                 sumX = sumX + X[K - 1];
             }
-            else if (lane == kLanesPerPair - 1) {
-                const uint32_t j = t - (kLanesPerPair - 1);  // lane 15 is at column t - 15 >= 1 whenever it is active
-                wM[j] = M[K - 1];
-                wX[j] = X[K - 1];
-                wY[j] = Y[K - 1];
+            else if (lane == G - 1) {
+                const uint32_t j = t - (G - 1);  // the last lane is at column t - (G-1) >= 1 whenever it is active
+                struct V3
+                {
+                    T m, x, y;
+                };
+                *reinterpret_cast<V3 *>(wbase + (j * kGroups + grp) * 3u) = V3{M[K - 1], X[K - 1], Y[K - 1]};
             }
         };
 
-        for (uint32_t g = 0; g < G; ++g) {
+        for (uint32_t g = 0; g < n_super; ++g) {
             const int32_t tau = static_cast<int32_t>(g) - static_cast<int32_t>(kLag * wave);
             if (tau >= 0 && static_cast<uint32_t>(tau) < n_rounds * Bs) {
                 const uint32_t round = static_cast<uint32_t>(tau) / Bs, c = static_cast<uint32_t>(tau) % Bs;
@@ -621,15 +663,18 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                     masks_reload(t0);
                     const uint32_t t1 = min(t0 + 31u, Tmax);
                     for (uint32_t t = t0; t <= t1; ++t) {
+                        ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
                         if ((t > lane) && (t <= Tg)) {
                             if (t & 1u)
                                 step(t, aM, aX, aY, bM, bX, bY);
                             else
                                 step(t, bM, bX, bY, aM, aX, aY);
                         }
-                        ring_fetch(t + 1);
+                        curM = nxtM;
+                        curX = nxtX;
+                        curY = nxtY;
                     }
-                    if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == kLanesPerPair - 1) {
+                    if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == G - 1) {
                         const T res = sumM + sumX;
                         reinterpret_cast<T *>(a.out_raw)[pair] = res;
                         if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))
@@ -754,11 +799,11 @@ hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const Kernel
     return uniform_gcp ? launch_k<float, true, 1>(rows_per_lane, a, s) : launch_k<float, false, 1>(rows_per_lane, a, s);
 }
 
-template <typename T, int K, bool UG, int WP>
+template <typename T, int K, bool UG, int WP, int G>
 static hipError_t launch_team_one(const KernelArgs &a, void *carry, uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
-    const size_t shmem = team_lds_bytes(a.lds_words_per_group, WP, sizeof(T));
-    auto kern = pairhmm_team_kernel<T, K, UG, WP>;
+    const size_t shmem = team_lds_bytes(a.lds_words_per_group, WP, sizeof(T), G);
+    auto kern = pairhmm_team_kernel<T, K, UG, WP, G>;
     if (shmem > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            static_cast<int>(shmem));
@@ -768,33 +813,42 @@ static hipError_t launch_team_one(const KernelArgs &a, void *carry, uint32_t car
     return hipGetLastError();
 }
 
-template <typename T, int K>
-static hipError_t launch_team_t(bool ug, int waves_per_team, const KernelArgs &a, void *carry, uint32_t carry_stride,
+template <typename T, int K, int G>
+static hipError_t launch_team_g(bool ug, int waves_per_team, const KernelArgs &a, void *carry, uint32_t carry_stride,
                                 uint32_t teams, hipStream_t s)
 {
-    if (a.n_pairs == 0 && !a.n_pairs_dev) return hipSuccess;
     if (waves_per_team == 8)
-        return ug ? launch_team_one<T, K, true, 8>(a, carry, carry_stride, teams, s)
-                  : launch_team_one<T, K, false, 8>(a, carry, carry_stride, teams, s);
+        return ug ? launch_team_one<T, K, true, 8, G>(a, carry, carry_stride, teams, s)
+                  : launch_team_one<T, K, false, 8, G>(a, carry, carry_stride, teams, s);
     if (waves_per_team == 4)
-        return ug ? launch_team_one<T, K, true, 4>(a, carry, carry_stride, teams, s)
-                  : launch_team_one<T, K, false, 4>(a, carry, carry_stride, teams, s);
+        return ug ? launch_team_one<T, K, true, 4, G>(a, carry, carry_stride, teams, s)
+                  : launch_team_one<T, K, false, 4, G>(a, carry, carry_stride, teams, s);
     if (waves_per_team == 1)
-        return ug ? launch_team_one<T, K, true, 1>(a, carry, carry_stride, teams, s)
-                  : launch_team_one<T, K, false, 1>(a, carry, carry_stride, teams, s);
+        return ug ? launch_team_one<T, K, true, 1, G>(a, carry, carry_stride, teams, s)
+                  : launch_team_one<T, K, false, 1, G>(a, carry, carry_stride, teams, s);
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, const KernelArgs &a, float *carry, uint32_t carry_stride,
-                              uint32_t teams, hipStream_t s)
+template <typename T, int K>
+static hipError_t launch_team_t(bool ug, int waves_per_team, int lanes_per_pair, const KernelArgs &a, void *carry,
+                                uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
-    return launch_team_t<float, kStripedRowsF32>(uniform_gcp, waves_per_team, a, carry, carry_stride, teams, s);
+    if (a.n_pairs == 0 && !a.n_pairs_dev) return hipSuccess;
+    if (lanes_per_pair == 64) return launch_team_g<T, K, 64>(ug, waves_per_team, a, carry, carry_stride, teams, s);
+    if (lanes_per_pair == 16) return launch_team_g<T, K, 16>(ug, waves_per_team, a, carry, carry_stride, teams, s);
+    return hipErrorInvalidValue;
 }
 
-hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, const KernelArgs &a, double *carry, uint32_t carry_stride,
-                              uint32_t teams, hipStream_t s)
+hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, float *carry,
+                              uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
-    return launch_team_t<double, kStripedRowsF64>(uniform_gcp, waves_per_team, a, carry, carry_stride, teams, s);
+    return launch_team_t<float, kStripedRowsF32>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
+}
+
+hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, double *carry,
+                              uint32_t carry_stride, uint32_t teams, hipStream_t s)
+{
+    return launch_team_t<double, kStripedRowsF64>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
 }
 
 hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,

@@ -248,11 +248,14 @@ def test_device_side_read_preparation_matches_host_logic(engine):
         assert np.array_equal(r_dev.view(np.uint32), r_host.view(np.uint32)) and np.array_equal(l_dev, l_host, equal_nan=True)
 
 
+@pytest.mark.parametrize("lanes", [16, 64])
 @pytest.mark.parametrize("waves", [1, 4, 8])
-def test_team_kernel_every_width(engine, waves, monkeypatch):
-    # the multi-wavefront-per-pair pipeline must give the same bits whatever the number of waves per team; mixed read
-    # lengths inside a team exercise the late-join of pairs with fewer stripes, and the fp64 re-run takes the same path
+def test_team_kernel_every_width(engine, waves, lanes, monkeypatch):
+    # the multi-wavefront-per-pair pipeline must give the same bits whatever the number of waves per team and whether a
+    # wave holds four pairs (16 lanes each) or one (64 lanes); mixed read lengths inside a team exercise the late-join of
+    # pairs with fewer stripes, and the fp64 re-run takes the same path
     monkeypatch.setenv("PHMM_FORCE_TEAM_WAVES", str(waves))
+    monkeypatch.setenv("PHMM_FORCE_TEAM_LANES", str(lanes))
     rng = np.random.default_rng(20 + waves)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     reads, haps, pairs = [], [], []
