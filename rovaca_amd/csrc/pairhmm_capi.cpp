@@ -127,6 +127,7 @@ struct phmm_context
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
     struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
+    std::vector<uint32_t> bin_hist, bin_slot;  // host scratch of the length binning, kept between calls
 };
 
 struct Bin
@@ -191,7 +192,9 @@ struct phmm_resident
     DevBuf<uint32_t> planes;
     DevBuf<float> raw32;
     DevBuf<double> raw64;
-    DevBuf<uint32_t> rescue_list, rescue_count;
+    DevBuf<uint32_t> rescue_list;
+    DevView<uint32_t> rescue_count;  // inside raw32, behind the sums
+    bool queue_is_empty = false;     // the set-up launch has just zeroed rescue_count
     DevBuf<float> carry32;
     DevBuf<double> carry64;
     std::vector<Bin> bins;
@@ -302,6 +305,23 @@ void phmm_release(phmm_context *c, phmm_resident *rb)
     delete rb;
 }
 
+// PHMM_PHASE_TIMING=1: host phases of phmm_compute on stderr (tuning aid)
+struct PhaseClock
+{
+    bool on = getenv("PHMM_PHASE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    double us[8] = {0};
+    void lap(int i)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        us[i] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+};
+static thread_local PhaseClock *g_phase = nullptr;
+#define PHASE(i) do { if (g_phase) g_phase->lap(i); } while (0)
+
 static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
 {
     if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
@@ -337,6 +357,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     if (phmm::team_lds_bytes((uint32_t)phmm::kPlanes * phmm::planes_words(max_hap), 8, 8, 16) > 160u * 1024u)
         return fail(PHMM_E_INVALID, "phmm_upload: haplotype of %u bases exceeds the LDS plane budget", max_hap);
 
+    PHASE(0);
     rb->bins.clear();
     rb->last_rescued = 0;
     rb->last_kernel_ms = 0.0;
@@ -345,58 +366,6 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     rb->n_haps = b->n_haps;
     rb->max_hap_len = max_hap;
     rb->max_read_len = max_read;
-
-    // ---- pair list (materialise the cross product), length binning ----
-    std::vector<uint32_t> pr(n_pairs), ph(n_pairs);
-    if (cross) {
-        for (uint64_t p = 0; p < n_pairs; ++p) {
-            pr[p] = (uint32_t)(p / b->n_haps);
-            ph[p] = (uint32_t)(p % b->n_haps);
-        }
-    }
-    else {
-        for (uint64_t p = 0; p < n_pairs; ++p) {
-            if (b->pair_read[p] >= b->n_reads || b->pair_hap[p] >= b->n_haps)
-                return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)p);
-            pr[p] = b->pair_read[p];
-            ph[p] = b->pair_hap[p];
-        }
-    }
-    // key = (rows per lane, haplotype length): one launch per rows-per-lane value, waves of near-equal sweep length.
-    // Pairs with a read above 256 bases or a haplotype above the single-pass LDS budget go to the striped kernel
-    // (class 17 here), ordered by (number of stripes, haplotype length).
-    std::vector<uint64_t> keys(n_pairs);
-    uint64_t cells = 0;
-    for (uint64_t p = 0; p < n_pairs; ++p) {
-        const uint32_t R = b->read_len[pr[p]], H = b->hap_len[ph[p]];
-        uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
-        cells += (uint64_t)R * H;
-        if (K > (uint32_t)phmm::kMaxRowsPerLane || H > kSinglePassMaxHap) {
-            const uint32_t S = phmm::kLanesPerPair * phmm::kStripedRowsF32;
-            const uint64_t stripes = std::min<uint64_t>((R + S - 1) / S, 63u);
-            keys[p] = (17ull << 58) | (stripes << 52) | ((uint64_t)(0xFFFFFu - H) << 32) | p;  // longest haplotypes first
-        }
-        else {
-            keys[p] = ((uint64_t)K << 58) | ((uint64_t)(0xFFFFFu - H) << 32) | p;  // H < 2^20; longest first: short tail
-        }
-    }
-    std::sort(keys.begin(), keys.end());
-    std::vector<uint32_t> order(n_pairs);
-    for (uint64_t i = 0; i < n_pairs; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
-    for (uint64_t i = 0; i < n_pairs;) {
-        const int cls = (int)(keys[i] >> 58);
-        uint64_t j = i;
-        uint32_t hmax = 0, rmax = 0;
-        while (j < n_pairs && (int)(keys[j] >> 58) == cls) {
-            hmax = std::max(hmax, b->hap_len[ph[order[j]]]);
-            rmax = std::max(rmax, b->read_len[pr[order[j]]]);
-            ++j;
-        }
-        const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
-        rb->bins.push_back(Bin{cls == 17 ? 0 : cls, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax});
-        i = j;
-    }
-    rb->cells = cells;
 
     // the Rovaca case -- one gap-continuation penalty for every base and deletion gap-open == insertion gap-open
     // (read_record.cpp:205-210, pairhmm_internal.cpp:425) -- selects the kernel variant that shares those constants
@@ -415,49 +384,182 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     }
     rb->uniform_gcp = ug;
 
-    // ---- haplotype plane layout ----
-    std::vector<uint32_t> plane_off(b->n_haps), owner;
+    // ---- stage layout: every input travels in ONE pinned buffer and ONE copy; the index arrays are built in place ----
     uint64_t slots = 0;
-    for (uint32_t h = 0; h < b->n_haps; ++h) {
-        plane_off[h] = (uint32_t)(slots * phmm::kPlanes);
-        slots += phmm::planes_words(b->hap_len[h]);
-    }
+    for (uint32_t h = 0; h < b->n_haps; ++h) slots += phmm::planes_words(b->hap_len[h]);
     if (slots * phmm::kPlanes > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_upload: haplotype table too large");
-    owner.resize(slots);
-    {
-        uint64_t s = 0;
-        for (uint32_t h = 0; h < b->n_haps; ++h)
-            for (uint32_t w = 0; w < phmm::planes_words(b->hap_len[h]); ++w) owner[s++] = h;
-    }
-
-    // ---- upload: pack every input into the pinned stage, one copy ----
     hipStream_t st = c->stream;
     HIP_TRY(hipStreamSynchronize(st));  // the previous pass of this resident batch no longer reads the stage or the blob
-    struct Piece
-    {
-        const void *src;
-        size_t bytes, at;
-    };
-    std::vector<Piece> pieces;
     size_t total = 0;
-    auto reserve = [&](const void *src, size_t bytes) {
+    auto reserve = [&](size_t bytes) {
         const size_t at = total;
-        pieces.push_back(Piece{src, bytes, at});
         total += (bytes + 255) & ~size_t(255);
         return at;
     };
-    const size_t o_bases = reserve(b->read_bases, read_bytes), o_qual = reserve(b->read_qual, read_bytes);
-    const size_t o_mapq = reserve(prep ? prep->read_mapq : nullptr, prep ? b->n_reads : 0);
-    const size_t o_roff = reserve(b->read_off, b->n_reads * sizeof(uint32_t)), o_rlen = reserve(b->read_len, b->n_reads * sizeof(uint32_t));
-    const size_t o_hap = reserve(b->hap_bases, hap_bytes);
-    const size_t o_hoff = reserve(b->hap_off, b->n_haps * sizeof(uint32_t)), o_hlen = reserve(b->hap_len, b->n_haps * sizeof(uint32_t));
-    const size_t o_pr = reserve(pr.data(), n_pairs * sizeof(uint32_t)), o_ph = reserve(ph.data(), n_pairs * sizeof(uint32_t));
-    const size_t o_order = reserve(order.data(), n_pairs * sizeof(uint32_t));
-    const size_t o_poff = reserve(plane_off.data(), b->n_haps * sizeof(uint32_t)), o_owner = reserve(owner.data(), slots * sizeof(uint32_t));
+    const size_t o_bases = reserve(read_bytes), o_qual = reserve(read_bytes);
+    const size_t o_mapq = reserve(prep ? b->n_reads : 0);
+    const size_t o_roff = reserve(b->n_reads * sizeof(uint32_t)), o_rlen = reserve(b->n_reads * sizeof(uint32_t));
+    const size_t o_hap = reserve(hap_bytes);
+    const size_t o_hoff = reserve(b->n_haps * sizeof(uint32_t)), o_hlen = reserve(b->n_haps * sizeof(uint32_t));
+    const size_t o_pr = reserve(n_pairs * sizeof(uint32_t)), o_ph = reserve(n_pairs * sizeof(uint32_t));
+    const size_t o_order = reserve(n_pairs * sizeof(uint32_t));
+    const size_t o_poff = reserve(b->n_haps * sizeof(uint32_t)), o_owner = reserve(slots * sizeof(uint32_t));
     HIP_TRY(rb->stage.ensure(total));
     HIP_TRY(rb->blob.alloc(total));
-    for (const Piece &pc : pieces)
-        if (pc.bytes) memcpy(static_cast<uint8_t *>(rb->stage.p) + pc.at, pc.src, pc.bytes);
+    uint8_t *stage = static_cast<uint8_t *>(rb->stage.p);
+    if (read_bytes) {
+        memcpy(stage + o_bases, b->read_bases, read_bytes);
+        memcpy(stage + o_qual, b->read_qual, read_bytes);
+    }
+    if (prep && b->n_reads) memcpy(stage + o_mapq, prep->read_mapq, b->n_reads);
+    if (b->n_reads) {
+        memcpy(stage + o_roff, b->read_off, b->n_reads * sizeof(uint32_t));
+        memcpy(stage + o_rlen, b->read_len, b->n_reads * sizeof(uint32_t));
+    }
+    if (hap_bytes) memcpy(stage + o_hap, b->hap_bases, hap_bytes);
+    if (b->n_haps) {
+        memcpy(stage + o_hoff, b->hap_off, b->n_haps * sizeof(uint32_t));
+        memcpy(stage + o_hlen, b->hap_len, b->n_haps * sizeof(uint32_t));
+    }
+    uint32_t *pr = reinterpret_cast<uint32_t *>(stage + o_pr), *ph = reinterpret_cast<uint32_t *>(stage + o_ph);
+    uint32_t *order = reinterpret_cast<uint32_t *>(stage + o_order);
+    {
+        // haplotype plane layout
+        uint32_t *plane_off = reinterpret_cast<uint32_t *>(stage + o_poff), *owner = reinterpret_cast<uint32_t *>(stage + o_owner);
+        uint64_t s = 0;
+        for (uint32_t h = 0; h < b->n_haps; ++h) {
+            plane_off[h] = (uint32_t)(s * phmm::kPlanes);
+            for (uint32_t w = 0; w < phmm::planes_words(b->hap_len[h]); ++w) owner[s++] = h;
+        }
+    }
+    PHASE(1);
+
+    // ---- pair list (materialise the cross product) and length binning ----
+    // Order = (class, haplotype length descending, pair index).  Class = rows per lane 1..16 for the single-pass kernels
+    // (one launch each, waves of near-equal sweep length, the longest first so that the tail is short); pairs with a read
+    // above 256 bases or a haplotype above the single-pass LDS budget go to the striped kernel, ordered by number of stripes.
+    // Done as a counting sort over (class, length): a comparison sort was the largest host cost of a region-sized call.
+    constexpr uint32_t kClasses = 17 + 64;  // 1..16, then 17 + min(stripes, 63)
+    auto class_of = [](uint32_t R, uint32_t H) -> uint32_t {
+        const uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
+        if (K > (uint32_t)phmm::kMaxRowsPerLane || H > kSinglePassMaxHap) {
+            const uint32_t S = phmm::kLanesPerPair * phmm::kStripedRowsF32;
+            return 17u + std::min<uint32_t>((R + S - 1) / S, 63u);
+        }
+        return K;
+    };
+    uint32_t min_hap = max_hap;
+    for (uint32_t h = 0; h < b->n_haps; ++h) min_hap = std::min(min_hap, b->hap_len[h]);
+    const uint32_t hrange = b->n_haps ? max_hap - min_hap + 1 : 1;
+    uint32_t rank[kClasses], n_used = 0, class_rmax[kClasses];
+    {
+        bool used[kClasses] = {false};
+        const bool long_hap = max_hap > kSinglePassMaxHap;
+        for (uint32_t r = 0; r < b->n_reads; ++r) {
+            used[class_of(b->read_len[r], 1)] = true;
+            if (long_hap) used[class_of(b->read_len[r], max_hap)] = true;
+        }
+        for (uint32_t k = 0; k < kClasses; ++k) {
+            rank[k] = n_used;
+            class_rmax[k] = 0;
+            if (used[k]) ++n_used;
+        }
+    }
+    uint64_t cells = 0;
+    const uint64_t table = (uint64_t)n_used * hrange;
+    if (table <= std::max<uint64_t>(4 * n_pairs, 1u << 16)) {
+        std::vector<uint32_t> &hist = c->bin_hist, &slot = c->bin_slot;
+        hist.assign(table + 1, 0);
+        slot.resize(n_pairs);
+        auto visit = [&](uint64_t p, uint32_t r, uint32_t h) {
+            const uint32_t R = b->read_len[r], H = b->hap_len[h];
+            const uint32_t k = class_of(R, H);
+            class_rmax[k] = std::max(class_rmax[k], R);
+            const uint32_t at = rank[k] * hrange + (max_hap - H);
+            pr[p] = r;
+            ph[p] = h;
+            slot[p] = at;
+            ++hist[at + 1];
+            cells += (uint64_t)R * H;
+        };
+        if (cross) {
+            uint64_t p = 0;
+            for (uint32_t r = 0; r < b->n_reads; ++r)
+                for (uint32_t h = 0; h < b->n_haps; ++h) visit(p++, r, h);
+        }
+        else {
+            for (uint64_t p = 0; p < n_pairs; ++p) {
+                if (b->pair_read[p] >= b->n_reads || b->pair_hap[p] >= b->n_haps)
+                    return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)p);
+                visit(p, b->pair_read[p], b->pair_hap[p]);
+            }
+        }
+        for (uint64_t i = 0; i < table; ++i) hist[i + 1] += hist[i];  // hist[i] = first position of slot i
+        // bins: classes 1..16 one each, every striped class together
+        for (uint32_t k = 1; k < kClasses;) {
+            uint32_t k_end = k < 17 ? k + 1 : kClasses;
+            const uint32_t lo = rank[k], hi = k_end < kClasses ? rank[k_end] : n_used;
+            const uint32_t first = hist[(uint64_t)lo * hrange], end = hist[(uint64_t)hi * hrange];
+            if (end > first) {
+                uint32_t hmax = 0, rmax = 0;
+                for (uint32_t kk = k; kk < k_end; ++kk) rmax = std::max(rmax, class_rmax[kk]);
+                for (uint32_t rk = lo; rk < hi; ++rk)  // the longest haplotype of the bin: first occupied slot of a class
+                    for (uint32_t d = 0; d < hrange; ++d)
+                        if (hist[(uint64_t)rk * hrange + d + 1] > hist[(uint64_t)rk * hrange + d]) {
+                            hmax = std::max(hmax, max_hap - d);
+                            break;
+                        }
+                const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
+                rb->bins.push_back(Bin{k < 17 ? (int)k : 0, first, end - first, plane_words, hmax, rmax});
+            }
+            k = k_end;
+        }
+        for (uint64_t p = 0; p < n_pairs; ++p) order[hist[slot[p]]++] = (uint32_t)p;
+    }
+    else {
+        // sparse length distribution: comparison sort on (class, length, index)
+        std::vector<uint64_t> keys(n_pairs);
+        for (uint64_t p = 0; p < n_pairs; ++p) {
+            uint32_t r, h;
+            if (cross) {
+                r = (uint32_t)(p / b->n_haps);
+                h = (uint32_t)(p % b->n_haps);
+            }
+            else {
+                r = b->pair_read[p];
+                h = b->pair_hap[p];
+                if (r >= b->n_reads || h >= b->n_haps)
+                    return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)p);
+            }
+            pr[p] = r;
+            ph[p] = h;
+            const uint32_t R = b->read_len[r], H = b->hap_len[h];
+            cells += (uint64_t)R * H;
+            keys[p] = ((uint64_t)class_of(R, H) << 56) | ((uint64_t)(0xFFFFFu - H) << 32) | p;  // H < 2^20
+        }
+        std::sort(keys.begin(), keys.end());
+        for (uint64_t i = 0; i < n_pairs; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+        for (uint64_t i = 0; i < n_pairs;) {
+            const uint32_t k = (uint32_t)(keys[i] >> 56);
+            const int cls = k < 17 ? (int)k : 17;
+            uint64_t j = i;
+            uint32_t hmax = 0, rmax = 0;
+            while (j < n_pairs) {
+                const uint32_t kj = (uint32_t)(keys[j] >> 56);
+                if ((kj < 17 ? (int)kj : 17) != cls) break;
+                hmax = std::max(hmax, b->hap_len[ph[order[j]]]);
+                rmax = std::max(rmax, b->read_len[pr[order[j]]]);
+                ++j;
+            }
+            const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
+            rb->bins.push_back(Bin{cls == 17 ? 0 : cls, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax});
+            i = j;
+        }
+    }
+    rb->cells = cells;
+    PHASE(2);
+
+    // ---- upload ----
     if (total) HIP_TRY(hipMemcpyAsync(rb->blob.p, rb->stage.p, total, hipMemcpyHostToDevice, st));
     uint8_t *base = rb->blob.p;
     rb->read_bases = {base + o_bases, (size_t)read_bytes};
@@ -484,18 +586,40 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
         HIP_TRY(rb->read_gcp.upload(b->read_gcp, read_bytes, st));
     }
     HIP_TRY(rb->planes.alloc(slots * phmm::kPlanes));
-    HIP_TRY(rb->raw32.alloc(n_pairs));
+    // the rescue count lives behind the fp32 sums so that both come back in one copy
+    const size_t count_at = (n_pairs + 63) & ~size_t(63);
+    HIP_TRY(rb->raw32.alloc(count_at + 64));
+    rb->rescue_count = {reinterpret_cast<uint32_t *>(rb->raw32.p + count_at), 1};
     HIP_TRY(rb->raw64.alloc(n_pairs));
     HIP_TRY(rb->rescue_list.alloc(n_pairs));
-    HIP_TRY(rb->rescue_count.alloc(1));
-    if (prep && b->n_reads)  // H3 + H4 on the device, in place on the uploaded raw qualities
-        HIP_TRY(phmm::launch_prep_reads(rb->read_bases.p, rb->read_qual.p, rb->read_ins.p, rb->read_gcp.p, rb->read_off.p,
-                                        rb->read_len.p, rb->read_mapq.p, b->n_reads, prep->min_quality_threshold,
-                                        prep->pcr_model, prep->gap_open, prep->gap_cont, st));
-    if (n_pairs)
-        HIP_TRY(phmm::launch_hap_planes(rb->hap_bases.p, rb->hap_off.p, rb->hap_len.p, rb->plane_off.p, rb->word_owner.p,
-                                        (uint32_t)slots, rb->planes.p, st));
+    {
+        // H3 + H4 on the device (in place on the uploaded raw qualities) when asked, haplotype planes, empty rescue queue
+        phmm::SetupArgs sa{};
+        sa.hap_bases = rb->hap_bases.p;
+        sa.hap_off = rb->hap_off.p;
+        sa.hap_len = rb->hap_len.p;
+        sa.plane_off = rb->plane_off.p;
+        sa.word_owner = rb->word_owner.p;
+        sa.n_words = n_pairs ? (uint32_t)slots : 0;
+        sa.planes = rb->planes.p;
+        sa.read_bases = rb->read_bases.p;
+        sa.read_qual = rb->read_qual.p;
+        sa.read_gop = rb->read_ins.p;
+        sa.read_gcp = rb->read_gcp.p;
+        sa.read_off = rb->read_off.p;
+        sa.read_len = rb->read_len.p;
+        sa.read_mapq = rb->read_mapq.p;
+        sa.n_prep_reads = prep ? b->n_reads : 0;
+        sa.min_q = prep ? prep->min_quality_threshold : 0;
+        sa.pcr_model = prep ? prep->pcr_model : 0;
+        sa.gap_open = prep ? prep->gap_open : 0;
+        sa.gap_cont = prep ? prep->gap_cont : 0;
+        sa.rescue_count = rb->rescue_count.p;
+        HIP_TRY(phmm::launch_setup(sa, st));
+        rb->queue_is_empty = true;
+    }
     if (!prep) HIP_TRY(hipStreamSynchronize(st));  // read_ins / read_del / read_gcp were copied straight from caller memory
+    PHASE(3);
     return PHMM_OK;
 }
 
@@ -516,7 +640,8 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
 
 static int sweep_fp32(phmm_context *c, phmm_resident *rb)
 {
-    if (rb->n_pairs) HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, sizeof(uint32_t), c->stream));
+    if (rb->n_pairs && !rb->queue_is_empty) HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, sizeof(uint32_t), c->stream));
+    rb->queue_is_empty = false;
     const bool fan_out = rb->bins.size() > 1;
     if (fan_out) {
         HIP_TRY(hipEventRecord(c->fork, c->stream));
@@ -649,16 +774,21 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t n = rb->n_pairs;
     const bool want = (out_raw_f32 || out_log10) && n;
-    // results come back through pinned staging: [n floats][rescue count][n doubles when anything was rescued]
-    const size_t off_cnt = (n * sizeof(float) + 255) & ~size_t(255);
+    // results come back through pinned staging: [n floats, padding, rescue count][n doubles when anything was rescued]
+    const size_t count_at = (n + 63) & ~size_t(63);
+    const size_t off_cnt = count_at * sizeof(float);
     const size_t off64 = off_cnt + 256;
     if (n) {
         HIP_TRY(rb->out_stage.ensure(off64 + n * sizeof(double)));
-        if (want) HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off_cnt, rb->rescue_count.p, sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, c->stream));
+        if (want)
+            HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, off_cnt + sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        else
+            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off_cnt, rb->rescue_count.p, sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    PHASE(4);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (polling hipStreamQuery instead gains nothing: measured)
+    PHASE(5);
     if (n) rb->last_rescued = *reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(rb->out_stage.p) + off_cnt);
     const bool want64 = out_log10 && rb->last_rescued && n;
     if (want64) {
@@ -681,6 +811,7 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
             }
         }
     }
+    PHASE(6);
     if (stats) {
         stats->cells = rb->cells;
         stats->n_rescued = rb->last_rescued;
@@ -714,6 +845,8 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
         if (!c->scratch) return fail(PHMM_E_NOMEM, "phmm_compute: out of host memory");
     }
     phmm_resident *rb = c->scratch;
+    PhaseClock clock;
+    g_phase = clock.on ? &clock : nullptr;
     int rc = upload_into(c, b, rb);
     if (rc != PHMM_OK) return rc;
     // one pass; the events are read only after the download's synchronisation (no extra round trip for the timing)
@@ -721,15 +854,21 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
     rc = phmm_sweep(c, rb);
     if (rc != PHMM_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    rc = phmm_download(c, rb, out_raw_f32, out_log10, nullptr);
+    rc = phmm_download(c, rb, out_raw_f32, out_log10, stats);
     if (rc == PHMM_OK && stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         rb->last_kernel_ms = ms;
-        rc = phmm_download(c, rb, nullptr, nullptr, stats);
+        stats->kernel_ms = ms;
     }
     if (rc == PHMM_OK && stats)
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (g_phase) {
+        PHASE(7);
+        fprintf(stderr, "phmm phases us: validate %.1f pack %.1f bin %.1f enqueue-upload %.1f enqueue-sweep %.1f wait %.1f finalize %.1f stats %.1f\n",
+                clock.us[0], clock.us[1], clock.us[2], clock.us[3], clock.us[4], clock.us[5], clock.us[6], clock.us[7]);
+        g_phase = nullptr;
+    }
     return rc;
 }
 

@@ -61,12 +61,26 @@ inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t car
 {
     return (size_t)teams * waves_per_team * (64u / (size_t)lanes_per_pair) * 3u * carry_stride;
 }
-hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
-                             const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,
-                             hipStream_t s);
-hipError_t launch_prep_reads(const uint8_t *read_bases, uint8_t *read_qual, uint8_t *read_gop, uint8_t *read_gcp,
-                             const uint32_t *read_off, const uint32_t *read_len, const uint8_t *read_mapq, uint32_t n_reads,
-                             int32_t min_q, int32_t pcr_model, uint8_t gap_open, uint8_t gap_cont, hipStream_t s);
+// batch set-up (one launch): optional device-side read preparation, haplotype bit planes, rescue queue reset
+constexpr int kSetupThreads = 128;
+struct SetupArgs
+{
+    // haplotype planes
+    const uint8_t *hap_bases;
+    const uint32_t *hap_off, *hap_len, *plane_off, *word_owner;
+    uint32_t n_words;
+    uint32_t *planes;
+    // read preparation (n_prep_reads = 0: the read table arrived prepared)
+    const uint8_t *read_bases;
+    uint8_t *read_qual, *read_gop, *read_gcp;
+    const uint32_t *read_off, *read_len;
+    const uint8_t *read_mapq;
+    uint32_t n_prep_reads;
+    int32_t min_q, pcr_model;
+    uint8_t gap_open, gap_cont;
+    uint32_t *rescue_count;  // zeroed if non-null
+};
+hipError_t launch_setup(const SetupArgs &a, hipStream_t s);
 
 }  // namespace phmm
 #endif

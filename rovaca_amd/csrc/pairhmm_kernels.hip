@@ -103,11 +103,11 @@ template <> struct Num<double>
 //   plane 5   : read symbol outside ACGTN: never matches (all zero)
 // Words past the haplotype end are zero.
 // ----------------------------------------------------------------------------------------------------
-__global__ void hap_planes_kernel(const uint8_t *__restrict__ hap_bases, const uint32_t *__restrict__ hap_off,
-                                  const uint32_t *__restrict__ hap_len, const uint32_t *__restrict__ plane_off,
-                                  const uint32_t *__restrict__ word_owner, uint32_t n_words, uint32_t *__restrict__ planes)
+__device__ __forceinline__ void hap_planes_word(const uint8_t *__restrict__ hap_bases, const uint32_t *__restrict__ hap_off,
+                                                const uint32_t *__restrict__ hap_len, const uint32_t *__restrict__ plane_off,
+                                                const uint32_t *__restrict__ word_owner, uint32_t n_words,
+                                                uint32_t *__restrict__ planes, uint32_t g)
 {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_words) return;
     // word_owner[g] = haplotype that owns global word slot g; the slot index inside that haplotype follows
     uint32_t h = word_owner[g];
@@ -745,13 +745,12 @@ __constant__ uint8_t kPcrCap[4][21] = {
     {40, 40, 40, 39, 39, 39, 38, 38, 37, 37, 36, 35, 34, 33, 32, 30, 28, 26, 23, 20, 17},   // AGGRESSIVE   adapter.h:14
     {40, 40, 40, 40, 39, 39, 39, 39, 39, 38, 38, 38, 37, 37, 37, 36, 36, 35, 34, 33, 33}};  // CONSERVATIVE adapter.h:15
 
-__global__ void prep_reads_kernel(const uint8_t *__restrict__ read_bases, uint8_t *__restrict__ read_qual,
-                                  uint8_t *__restrict__ read_gop, uint8_t *__restrict__ read_gcp,
-                                  const uint32_t *__restrict__ read_off, const uint32_t *__restrict__ read_len,
-                                  const uint8_t *__restrict__ read_mapq, int32_t min_q, int32_t pcr_model, uint8_t gap_open,
-                                  uint8_t gap_cont)
+__device__ __forceinline__ void prep_one_read(const uint8_t *__restrict__ read_bases, uint8_t *__restrict__ read_qual,
+                                              uint8_t *__restrict__ read_gop, uint8_t *__restrict__ read_gcp,
+                                              const uint32_t *__restrict__ read_off, const uint32_t *__restrict__ read_len,
+                                              const uint8_t *__restrict__ read_mapq, int32_t min_q, int32_t pcr_model,
+                                              uint8_t gap_open, uint8_t gap_cont, uint32_t r)
 {
-    const uint32_t r = blockIdx.x;
     const uint32_t off = read_off[r], n = read_len[r];
     const uint8_t mq = read_mapq[r];
     const uint8_t *bases = read_bases + off;
@@ -851,23 +850,26 @@ hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, int lanes_pe
     return launch_team_t<double, kStripedRowsF64>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
 }
 
-hipError_t launch_hap_planes(const uint8_t *hap_bases, const uint32_t *hap_off, const uint32_t *hap_len,
-                             const uint32_t *plane_off, const uint32_t *word_owner, uint32_t n_words, uint32_t *planes,
-                             hipStream_t s)
+// One launch sets a batch up: workgroups [0, n_prep_reads) prepare one read each (H3 + H4, only for batches that carry a
+// phmm_read_prep), the rest build the haplotype bit planes, one thread per 32-column word; the rescue queue is emptied on
+// the way.  A region-sized call is a chain of dependent launches and copies, each worth 5-10 us: fewer links, lower latency.
+__global__ void __launch_bounds__(kSetupThreads) setup_kernel(SetupArgs s)
 {
-    if (n_words == 0) return hipSuccess;
-    hipLaunchKernelGGL(hap_planes_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, hap_bases, hap_off, hap_len,
-                       plane_off, word_owner, n_words, planes);
-    return hipGetLastError();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && s.rescue_count) *s.rescue_count = 0;
+    if (blockIdx.x < s.n_prep_reads) {
+        prep_one_read(s.read_bases, s.read_qual, s.read_gop, s.read_gcp, s.read_off, s.read_len, s.read_mapq, s.min_q, s.pcr_model,
+                      s.gap_open, s.gap_cont, blockIdx.x);
+        return;
+    }
+    hap_planes_word(s.hap_bases, s.hap_off, s.hap_len, s.plane_off, s.word_owner, s.n_words, s.planes,
+                    (blockIdx.x - s.n_prep_reads) * kSetupThreads + threadIdx.x);
 }
 
-hipError_t launch_prep_reads(const uint8_t *read_bases, uint8_t *read_qual, uint8_t *read_gop, uint8_t *read_gcp,
-                             const uint32_t *read_off, const uint32_t *read_len, const uint8_t *read_mapq, uint32_t n_reads,
-                             int32_t min_q, int32_t pcr_model, uint8_t gap_open, uint8_t gap_cont, hipStream_t s)
+hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
 {
-    if (n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(prep_reads_kernel, dim3(n_reads), dim3(128), 0, s, read_bases, read_qual, read_gop, read_gcp, read_off,
-                       read_len, read_mapq, min_q, pcr_model, gap_open, gap_cont);
+    const uint32_t blocks = a.n_prep_reads + (a.n_words + kSetupThreads - 1) / kSetupThreads;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(setup_kernel, dim3(blocks), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 
