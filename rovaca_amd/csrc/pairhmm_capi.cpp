@@ -173,6 +173,7 @@ static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t m
 // single-pass kernels keep 16 pairs' haplotype planes in LDS per workgroup; longer haplotypes take the striped kernel
 constexpr uint32_t kSinglePassMaxHap = 4096;
 constexpr uint32_t kMaxLen = 1u << 20;
+constexpr uint32_t kWideMaxPairs = 1536;       // single-pass launches up to this many pairs run one pair per wave
 constexpr uint32_t kRescueMaxTeams = 4096;    // workgroups of the fp64 re-run (they stride over the rescue queue)
 constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
 
@@ -673,7 +674,17 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.rescue_list = rb->rescue_list.p;
         a.rescue_count = rb->rescue_count.p;
         if (bin.rows_per_lane > 0) {
-            HIP_TRY(phmm::launch_systolic_f32(bin.rows_per_lane, rb->uniform_gcp, a, stream));
+            // Few pairs: one pair per wave.  Four per wave would occupy count / 4 of the chip's 1024 SIMDs with one slow wave
+            // each; 64 lanes per pair makes the sweep of a pair about half as long (a quarter of the rows per lane, 48 more
+            // steps) at 1.8x the instructions, which is free while SIMDs idle.  Measured: a 432-pair region 85 -> 46 us, 1728 pairs 86 -> 68 us, no gain from 4000 pairs on, and a loss when
+            // several submissions share the chip, hence the low threshold.
+            int lanes = bin.count <= kWideMaxPairs ? 64 : 16;
+            if (const char *f = getenv("PHMM_FORCE_LANES")) {  // tests
+                const int l = atoi(f);
+                if (l == 16 || l == 64) lanes = l;
+            }
+            const int k = lanes == 64 ? (int)((bin.max_read_len + 63) / 64) : bin.rows_per_lane;
+            HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream));
         }
         else {
             const TeamShape sh = pick_team_shape(bin.count, bin.max_read_len, bin.max_hap_len, phmm::kStripedRowsF32);

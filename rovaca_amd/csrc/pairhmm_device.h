@@ -10,6 +10,7 @@ namespace phmm
 constexpr int kLanesPerPair = 16;     // one DPP row per (read, haplotype) pair; four pairs per wave64
 constexpr int kBlockThreads = 256;    // 4 waves = 16 pairs per workgroup
 constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take the single-pass kernel
+constexpr int kMaxRowsPerLaneWide = 4;  // same limit for the one-pair-per-wave shape: 64 * 4 rows
 constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other
 constexpr int kStripedRowsF32 = 8;   // rows per lane of the striped fp32 kernel (stripes of 256 read rows)
 constexpr int kStripedRowsF64 = 4;    // rows per lane of the striped fp64 kernel (stripes of 128 read rows)
@@ -44,7 +45,8 @@ struct KernelArgs
     const uint32_t *n_pairs_dev;
 };
 
-hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const KernelArgs &a, hipStream_t s);
+// lanes_per_pair 16: rows_per_lane = ceil(R / 16) in 1..kMaxRowsPerLane; 64: ceil(R / 64) in 1..kMaxRowsPerLaneWide
+hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool uniform_gcp, const KernelArgs &a, hipStream_t s);
 // striped ("team") kernels: a workgroup of waves_per_team waves (1, 4 or 8) sweeps four pairs; lds_words_per_group is
 // kPlanes * planes_words(longest haplotype of the launch); carry holds 3 * carry_stride values per (team, wave, group).
 // lanes_per_pair: 16 (four pairs per wave) or 64 (one pair per wave)

@@ -155,13 +155,19 @@ struct Rows
 // wins at 4 waves with a few spills outside the steady loop; K = 12..14 run best at 3 waves.
 #define PHMM_MIN_WAVES(T, K, UG) (sizeof(T) == 8 ? 2 : ((UG) && (K) <= 11) ? 4 : ((UG) && (K) <= 14) ? 3 : 1)
 
-template <typename T, int K, bool UG>
-__global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(T, K, UG)) pairhmm_systolic_kernel(KernelArgs a)
+// G = lanes per pair.  16: four pairs per wave (DPP row_shr), the throughput shape.  64: one pair per wave (DPP wave_shr) in
+// one-wave workgroups, the latency shape for launches with so few pairs that four-per-wave would leave most SIMDs empty (a
+// single region): a quarter of the rows per lane makes the sweep of a pair about twice as short.
+template <int G> constexpr int systolic_block_threads() { return G == 64 ? 64 : kBlockThreads; }
+
+template <typename T, int K, bool UG, int G>
+__global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHMM_MIN_WAVES(T, K, UG))
+    pairhmm_systolic_kernel(KernelArgs a)
 {
     extern __shared__ uint32_t lds[];
-    const uint32_t lane = threadIdx.x & 15u;                                    // lane inside the pair's 16-lane array
-    const uint32_t grp_in_block = threadIdx.x >> 4;                             // 0..15
-    const uint32_t gidx = blockIdx.x * (kBlockThreads / kLanesPerPair) + grp_in_block;
+    const uint32_t lane = threadIdx.x & (uint32_t)(G - 1);                      // lane inside the pair's G-lane array
+    const uint32_t grp_in_block = threadIdx.x / (uint32_t)G;                    // 0..15 (G = 16), 0 (G = 64)
+    const uint32_t gidx = blockIdx.x * (systolic_block_threads<G>() / G) + grp_in_block;
     const bool valid = gidx < a.n_pairs;
     const uint32_t pair = a.order[valid ? gidx : 0];
     const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
@@ -175,7 +181,7 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(T, K, UG)) pairh
     uint32_t *pl = lds + grp_in_block * a.lds_words_per_group;
     {
         const uint32_t *src = a.planes + a.plane_off[h];
-        for (uint32_t i = lane; i < kPlanes * W; i += kLanesPerPair) pl[i] = src[i];
+        for (uint32_t i = lane; i < kPlanes * W; i += G) pl[i] = src[i];
     }
 
     // ---- per-row constants (pairhmm_internal.cpp:466-480 == core/avx512_s.cpp:90-101) ----
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(T, K, UG)) pairh
     T M[K], X[K], Y[K];
     uint32_t cls_lo = 0, cls_hi = 0;  // 3-bit plane class per row, packed (K <= 16 -> 48 bits)
     const T init_y = Num<T>::init_const() / static_cast<T>(H);  // rovaca/avx_512_float.cc:32
-    const int pad = kLanesPerPair * K - static_cast<int>(R);    // rows [0, pad) are boundary replicas
+    const int pad = G * K - static_cast<int>(R);                  // rows [0, pad) are boundary replicas
     if (UG) {
         uint32_t c0 = a.read_gcp[roff] & 127u;
         P.p_gapm_r[0] = static_cast<T>(1.0) - ph2pr[c0];
@@ -238,15 +244,16 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(T, K, UG)) pairh
     __syncthreads();  // planes visible (each group only reads its own, but keep the block-wide fence simple)
 
     // ---- the sweep ----
-    const uint32_t Tg = valid ? H + (kLanesPerPair - 1) : 0;  // last step of this group
-    uint32_t Tmax = Tg;                                         // wave-uniform loop bound
-    Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
-    Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+    const uint32_t Tg = valid ? H + (G - 1) : 0;  // last step of this group
+    uint32_t Tmax = Tg;                           // wave-uniform loop bound
+    uint32_t Tmin = Tg;                           // until here every lane of the wave is busy once the pipeline is full
+    if (G == 16) {
+        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
+    }
     Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
-
-    uint32_t Tmin = Tg;  // until here every lane of the wave is busy once the pipeline is full
-    Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
-    Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
     Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
 
     uint32_t mask[K];
@@ -278,9 +285,9 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(T, K, UG)) pairh
 
     // one anti-diagonal.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it at this column.
     auto step = [&](T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
-        uM0 = dpp_row_shr1(uM0, M[K - 1]);
-        uX0 = dpp_row_shr1(uX0, X[K - 1]);
-        uY0 = dpp_row_shr1(uY0, Y[K - 1]);
+        uM0 = dpp_shr1<G>(uM0, M[K - 1]);
+        uX0 = dpp_shr1<G>(uX0, X[K - 1]);
+        uY0 = dpp_shr1<G>(uY0, Y[K - 1]);
         // Pass 1, bottom row first: Y' and M' read only the previous anti-diagonal, so walking upwards lets every
         // value be overwritten in place (row k's old M/X/Y are last read by row k+1, which is already done).
 #pragma unroll
@@ -320,7 +327,7 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(T, K, UG)) pairh
 
     uint32_t t = 1;
     // fill: lane l starts at step l + 1
-    const uint32_t Tfill = Tmax < (uint32_t)(kLanesPerPair - 1) ? Tmax : (uint32_t)(kLanesPerPair - 1);
+    const uint32_t Tfill = Tmax < (uint32_t)(G - 1) ? Tmax : (uint32_t)(G - 1);
     for (; t <= Tfill; ++t) {
         if ((t & 31u) == 1u) reload(t);
         if ((t > lane) && (t <= Tg)) step_t(t);
@@ -345,7 +352,7 @@ __global__ void __launch_bounds__(kBlockThreads, PHMM_MIN_WAVES(T, K, UG)) pairh
         if ((t & 31u) == 1u) reload(t);
         if (t <= Tg) step_t(t);
     }
-    if (valid && lane == kLanesPerPair - 1) {
+    if (valid && lane == G - 1) {
         const T res = sumM + sumX;
         reinterpret_cast<T *>(a.out_raw)[pair] = res;
         if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))  // pairhmm_internal.cpp:578: queue for fp64
@@ -772,30 +779,34 @@ __device__ __forceinline__ void prep_one_read(const uint8_t *__restrict__ read_b
 // ----------------------------------------------------------------------------------------------------
 // launchers (one instantiation per rows-per-lane K)
 // ----------------------------------------------------------------------------------------------------
-template <typename T, int K, bool UG>
+template <typename T, int K, bool UG, int G>
 static hipError_t launch_one(const KernelArgs &a, hipStream_t s)
 {
-    const uint32_t groups_per_block = kBlockThreads / kLanesPerPair;
+    constexpr uint32_t threads = systolic_block_threads<G>();
+    const uint32_t groups_per_block = threads / G;
     const uint32_t blocks = (a.n_pairs + groups_per_block - 1) / groups_per_block;
     const size_t shmem = static_cast<size_t>(groups_per_block) * a.lds_words_per_group * sizeof(uint32_t);
-    hipLaunchKernelGGL((pairhmm_systolic_kernel<T, K, UG>), dim3(blocks), dim3(kBlockThreads), shmem, s, a);
+    hipLaunchKernelGGL((pairhmm_systolic_kernel<T, K, UG, G>), dim3(blocks), dim3(threads), shmem, s, a);
     return hipGetLastError();
 }
 
-template <typename T, bool UG, int K>
+template <typename T, bool UG, int G, int K>
 static hipError_t launch_k(int k, const KernelArgs &a, hipStream_t s)
 {
-    if (k == K) return launch_one<T, K, UG>(a, s);
-    if constexpr (K < kMaxRowsPerLane)
-        return launch_k<T, UG, K + 1>(k, a, s);
+    if (k == K) return launch_one<T, K, UG, G>(a, s);
+    if constexpr (K < (G == 64 ? kMaxRowsPerLaneWide : kMaxRowsPerLane))
+        return launch_k<T, UG, G, K + 1>(k, a, s);
     else
         return hipErrorInvalidValue;
 }
 
-hipError_t launch_systolic_f32(int rows_per_lane, bool uniform_gcp, const KernelArgs &a, hipStream_t s)
+hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool uniform_gcp, const KernelArgs &a, hipStream_t s)
 {
     if (a.n_pairs == 0) return hipSuccess;
-    return uniform_gcp ? launch_k<float, true, 1>(rows_per_lane, a, s) : launch_k<float, false, 1>(rows_per_lane, a, s);
+    if (lanes_per_pair == 64)
+        return uniform_gcp ? launch_k<float, true, 64, 1>(rows_per_lane, a, s) : launch_k<float, false, 64, 1>(rows_per_lane, a, s);
+    if (lanes_per_pair != 16) return hipErrorInvalidValue;
+    return uniform_gcp ? launch_k<float, true, 16, 1>(rows_per_lane, a, s) : launch_k<float, false, 16, 1>(rows_per_lane, a, s);
 }
 
 template <typename T, int K, bool UG, int WP, int G>

@@ -63,12 +63,17 @@ def test_config2_sample_150x300(engine):
     _check_against_oracle(engine, synth.make_config("c2", scale=0.02))
 
 
-def test_config3_sample_mixed_lengths(engine):
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_config3_sample_mixed_lengths(engine, lanes, monkeypatch):
+    monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
     _check_against_oracle(engine, synth.make_config("c3", scale=0.02))
 
 
-def test_every_rows_per_lane_bin(engine):
-    # read lengths 1..256 hit every K = ceil(R/16) instantiation, including exact multiples of 16
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_every_rows_per_lane_bin(engine, lanes, monkeypatch):
+    # read lengths 1..256 hit every K = ceil(R/16) instantiation, including exact multiples of 16, in both shapes of the
+    # single-pass kernel: four pairs per wave (16 lanes each) and one pair per wave (64 lanes, K = ceil(R/64))
+    monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
     rng = np.random.default_rng(5)
     reads, haps, pairs = [], [], []
     acgt = np.frombuffer(b"ACGT", np.uint8)
@@ -89,8 +94,10 @@ def test_every_rows_per_lane_bin(engine):
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
-def test_general_gap_parameters(engine):
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_general_gap_parameters(engine, lanes, monkeypatch):
     # per-base ins / del / gcp all different: exercises the non-uniform-gcp kernel variant
+    monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
     rng = np.random.default_rng(6)
     b = synth.make_batch(seed=61, n_regions=4, reads=12, haps=4, read_len=(20, 250), hap_len=(40, 400))
     n = b.read_bases.shape[0]
