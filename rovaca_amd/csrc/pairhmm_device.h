@@ -13,7 +13,9 @@ constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take 
 constexpr int kMaxRowsPerLaneWide = 4;  // same limit for the one-pair-per-wave shape: 64 * 4 rows
 constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other
 constexpr int kStripedRowsF32 = 8;   // rows per lane of the striped fp32 kernel (stripes of 256 read rows)
-constexpr int kStripedRowsF64 = 4;    // rows per lane of the striped fp64 kernel (stripes of 128 read rows)
+// rows per lane of the striped fp64 kernel: instantiated for 4, 5 and 6 (stripes of 64, 80, 96 read rows with 16 lanes per
+// pair); the launch picks the one that wastes the fewest padding rows on the batch's read lengths
+constexpr int kStripedRowsF64Min = 4, kStripedRowsF64Max = 6;
 constexpr int kStripedGroupsPerBlock = 4;  // a team (1, 4 or 8 waves) of the striped kernel sweeps four pairs
 
 // 32-bit words per haplotype match plane (column j, 1-based, is bit 31-((j-1)&31) of word (j-1)>>5); one spare
@@ -52,7 +54,7 @@ hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool unifo
 // lanes_per_pair: 16 (four pairs per wave) or 64 (one pair per wave)
 hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, float *carry,
                               uint32_t carry_stride, uint32_t teams, hipStream_t s);
-hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, double *carry,
+hipError_t launch_striped_f64(int rows_per_lane, bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, double *carry,
                               uint32_t carry_stride, uint32_t teams, hipStream_t s);
 inline size_t team_lds_bytes(uint32_t plane_words_per_group, int waves_per_team, size_t value_bytes, int lanes_per_pair)
 {

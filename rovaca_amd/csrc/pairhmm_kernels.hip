@@ -855,10 +855,14 @@ hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, int lanes_pe
     return launch_team_t<float, kStripedRowsF32>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
 }
 
-hipError_t launch_striped_f64(bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, double *carry,
-                              uint32_t carry_stride, uint32_t teams, hipStream_t s)
+hipError_t launch_striped_f64(int rows_per_lane, bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a,
+                              double *carry, uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
-    return launch_team_t<double, kStripedRowsF64>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
+    static_assert(kStripedRowsF64Min == 4 && kStripedRowsF64Max == 6, "instantiate every rows-per-lane value in the range");
+    if (rows_per_lane == 4) return launch_team_t<double, 4>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (rows_per_lane == 5) return launch_team_t<double, 5>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (rows_per_lane == 6) return launch_team_t<double, 6>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
+    return hipErrorInvalidValue;
 }
 
 // One launch sets a batch up: workgroups [0, n_prep_reads) prepare one read each (H3 + H4, only for batches that carry a

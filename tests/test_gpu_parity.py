@@ -108,7 +108,11 @@ def test_general_gap_parameters(engine, lanes, monkeypatch):
     _check_against_oracle(engine, b)
 
 
-def test_rescue_path_fp64(engine):
+@pytest.mark.parametrize("rows", [0, 4, 5, 6])
+def test_rescue_path_fp64(engine, rows, monkeypatch):
+    # the fp64 re-run is instantiated for 4, 5 and 6 rows per lane (0: let the launch choose by padding)
+    if rows:
+        monkeypatch.setenv("PHMM_FORCE_F64_ROWS", str(rows))
     b = synth.make_batch(seed=62, n_regions=3, reads=16, haps=4, read_len=(100, 250), hap_len=(260, 500), sub_rate=0.15,
                          qual=30)
     raw, l10 = _check_against_oracle(engine, b)
