@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pairhmm_device.h"
 
 namespace phmm
@@ -613,7 +615,7 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
             curX = nxtX;
             curY = nxtY;
         };
-        auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
+        auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0, auto is_last) {
             // lane 0 keeps `old` = the row above at column t (boundary row or carry); lanes 1..15 take lane-1's last row
             uM0 = dpp_shr1<G>(curM, M[K - 1]);
             uX0 = dpp_shr1<G>(curX, X[K - 1]);
@@ -639,7 +641,7 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                 uM = M[k];
                 uX = X[k];
             }
-            if (last) {
+            if (is_last) {
                 sumM = sumM + M[K - 1];
                 sumX = sumX + X[K - 1];
             }
@@ -650,6 +652,22 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                     T m, x, y;
                 };
                 *reinterpret_cast<V3 *>(wbase + (j * kGroups + grp) * 3u) = V3{M[K - 1], X[K - 1], Y[K - 1]};
+            }
+        };
+        // 32 steps with every lane of the wave busy: no per-lane predicate, the two register sets swap roles without a move
+        auto superstep_full = [&](uint32_t t0, auto is_last) {
+#pragma unroll 1
+            for (uint32_t t = t0; t < t0 + 32u; t += 2) {
+                ring_fetch(t + 1);
+                step(t, aM, aX, aY, bM, bX, bY, is_last);
+                curM = nxtM;
+                curX = nxtX;
+                curY = nxtY;
+                ring_fetch(t + 2);
+                step(t + 1, bM, bX, bY, aM, aX, aY, is_last);
+                curM = nxtM;
+                curX = nxtX;
+                curY = nxtY;
             }
         };
 
@@ -669,17 +687,32 @@ __global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, 
                     const uint32_t t0 = 32u * c + 1u;
                     masks_reload(t0);
                     const uint32_t t1 = min(t0 + 31u, Tmax);
-                    for (uint32_t t = t0; t <= t1; ++t) {
-                        ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
-                        if ((t > lane) && (t <= Tg)) {
-                            if (t & 1u)
-                                step(t, aM, aX, aY, bM, bX, bY);
-                            else
-                                step(t, bM, bX, bY, aM, aX, aY);
+                    uint32_t Tmin = Tg;  // wave-uniform: the last step at which every group of the wave is still sweeping
+                    if (kGroups > 1) {
+                        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+                        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
+                    }
+                    Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
+                    if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
+                        // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
+                        if (v + 1 == max_stripes)
+                            superstep_full(t0, std::true_type{});
+                        else
+                            superstep_full(t0, std::false_type{});
+                    }
+                    else {
+                        for (uint32_t t = t0; t <= t1; ++t) {
+                            ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
+                            if ((t > lane) && (t <= Tg)) {
+                                if (t & 1u)
+                                    step(t, aM, aX, aY, bM, bX, bY, last);
+                                else
+                                    step(t, bM, bX, bY, aM, aX, aY, last);
+                            }
+                            curM = nxtM;
+                            curX = nxtX;
+                            curY = nxtY;
                         }
-                        curM = nxtM;
-                        curX = nxtX;
-                        curY = nxtY;
                     }
                     if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == G - 1) {
                         const T res = sumM + sumX;
