@@ -136,7 +136,15 @@ struct Bin
     uint32_t first, count;  // range of `order`
     uint32_t lds_words_per_group;
     uint32_t max_hap_len, max_read_len;
+    int queue;              // rescue queue the launch feeds: 0 for the single-pass bins, 1..4 for the striped size ranges
 };
+
+// Striped pairs are launched in up to four size ranges (48+ stripes of 128 rows, 24..47, 8..23, 1..7), each with the team
+// shape that fits it: a batch of a thousand long reads of very different sizes is otherwise bound by its longest pair
+// sweeping alone in a team sized for the average one.  Length classes: 1..16 single-pass rows per lane, then
+// 17 + 63 - min(stripes, 63).
+constexpr int kQueues = phmm::kRescueQueues;
+static inline int bin_id_of_class(uint32_t k) { return k < 17 ? (int)k : k < 33 ? 17 : k < 57 ? 18 : k < 73 ? 19 : 20; }
 
 // Geometry of a striped launch.  lanes: 16 puts four pairs in a wave, 64 gives a whole wave to one pair (chosen when the
 // launch has so few pairs that four-per-wave would leave most of the chip idle and the reads are long enough to fill 64-lane
@@ -159,7 +167,7 @@ static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t m
     const uint32_t stripes = (max_read + sh.lanes * rows_per_lane - 1) / (sh.lanes * rows_per_lane);
     const uint32_t supersteps = (max_hap + (uint32_t)sh.lanes - 1 + 31) / 32;
     const uint32_t lag = sh.lanes == 64 ? 6u : 4u;  // team_lag<G>() of the kernel
-    if (sh.lanes == 16 && batches < 2048 && stripes >= 8 && supersteps >= lag * 8 + 12)
+    if (batches < 2048 && stripes >= (sh.lanes == 64 ? 16u : 8u) && supersteps >= lag * 8 + 12)
         sh.waves = 8;
     else if (batches < 4096 && stripes >= 4 && supersteps >= lag * 4 + 12)
         sh.waves = 4;
@@ -438,14 +446,14 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     // ---- pair list (materialise the cross product) and length binning ----
     // Order = (class, haplotype length descending, pair index).  Class = rows per lane 1..16 for the single-pass kernels
     // (one launch each, waves of near-equal sweep length, the longest first so that the tail is short); pairs with a read
-    // above 256 bases or a haplotype above the single-pass LDS budget go to the striped kernel, ordered by number of stripes.
+    // above 256 bases or a haplotype above the single-pass LDS budget go to the striped kernel, most stripes first (longest-job-first fills the chip best).
     // Done as a counting sort over (class, length): a comparison sort was the largest host cost of a region-sized call.
-    constexpr uint32_t kClasses = 17 + 64;  // 1..16, then 17 + min(stripes, 63)
+    constexpr uint32_t kClasses = 17 + 64;  // 1..16, then 17 + 63 - min(stripes, 63)
     auto class_of = [](uint32_t R, uint32_t H) -> uint32_t {
         const uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
         if (K > (uint32_t)phmm::kMaxRowsPerLane || H > kSinglePassMaxHap) {
             const uint32_t S = phmm::kLanesPerPair * phmm::kStripedRowsF32;
-            return 17u + std::min<uint32_t>((R + S - 1) / S, 63u);
+            return 17u + (63u - std::min<uint32_t>((R + S - 1) / S, 63u));  // most stripes first: the longest pairs start first
         }
         return K;
     };
@@ -496,9 +504,10 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
             }
         }
         for (uint64_t i = 0; i < table; ++i) hist[i + 1] += hist[i];  // hist[i] = first position of slot i
-        // bins: classes 1..16 one each, every striped class together
+        // bins: classes 1..16 one each, the striped classes in four size ranges
         for (uint32_t k = 1; k < kClasses;) {
-            uint32_t k_end = k < 17 ? k + 1 : kClasses;
+            uint32_t k_end = k + 1;
+            while (k_end < kClasses && bin_id_of_class(k_end) == bin_id_of_class(k)) ++k_end;
             const uint32_t lo = rank[k], hi = k_end < kClasses ? rank[k_end] : n_used;
             const uint32_t first = hist[(uint64_t)lo * hrange], end = hist[(uint64_t)hi * hrange];
             if (end > first) {
@@ -511,7 +520,8 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
                             break;
                         }
                 const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
-                rb->bins.push_back(Bin{k < 17 ? (int)k : 0, first, end - first, plane_words, hmax, rmax});
+                const int id = bin_id_of_class(k);
+                rb->bins.push_back(Bin{id < 17 ? id : 0, first, end - first, plane_words, hmax, rmax, id < 17 ? 0 : id - 16});
             }
             k = k_end;
         }
@@ -541,19 +551,16 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
         std::sort(keys.begin(), keys.end());
         for (uint64_t i = 0; i < n_pairs; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
         for (uint64_t i = 0; i < n_pairs;) {
-            const uint32_t k = (uint32_t)(keys[i] >> 56);
-            const int cls = k < 17 ? (int)k : 17;
+            const int id = bin_id_of_class((uint32_t)(keys[i] >> 56));
             uint64_t j = i;
             uint32_t hmax = 0, rmax = 0;
-            while (j < n_pairs) {
-                const uint32_t kj = (uint32_t)(keys[j] >> 56);
-                if ((kj < 17 ? (int)kj : 17) != cls) break;
+            while (j < n_pairs && bin_id_of_class((uint32_t)(keys[j] >> 56)) == id) {
                 hmax = std::max(hmax, b->hap_len[ph[order[j]]]);
                 rmax = std::max(rmax, b->read_len[pr[order[j]]]);
                 ++j;
             }
             const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
-            rb->bins.push_back(Bin{cls == 17 ? 0 : cls, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax});
+            rb->bins.push_back(Bin{id < 17 ? id : 0, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax, id < 17 ? 0 : id - 16});
             i = j;
         }
     }
@@ -590,7 +597,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     // the rescue count lives behind the fp32 sums so that both come back in one copy
     const size_t count_at = (n_pairs + 63) & ~size_t(63);
     HIP_TRY(rb->raw32.alloc(count_at + 64));
-    rb->rescue_count = {reinterpret_cast<uint32_t *>(rb->raw32.p + count_at), 1};
+    rb->rescue_count = {reinterpret_cast<uint32_t *>(rb->raw32.p + count_at), (size_t)kQueues};
     HIP_TRY(rb->raw64.alloc(n_pairs));
     HIP_TRY(rb->rescue_list.alloc(n_pairs));
     {
@@ -641,15 +648,36 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
 
 static int sweep_fp32(phmm_context *c, phmm_resident *rb)
 {
-    if (rb->n_pairs && !rb->queue_is_empty) HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, sizeof(uint32_t), c->stream));
+    if (rb->n_pairs && !rb->queue_is_empty) HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, kQueues * sizeof(uint32_t), c->stream));
     rb->queue_is_empty = false;
     const bool fan_out = rb->bins.size() > 1;
     if (fan_out) {
         HIP_TRY(hipEventRecord(c->fork, c->stream));
         for (int i = 0; i < phmm_context::kSideStreams; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
     }
+    // striped launches run side by side on different streams: each gets its own slice of the carry buffer, sized up front
+    struct StripedPlan
+    {
+        TeamShape sh;
+        uint32_t teams;
+        size_t carry_at;
+    };
+    std::vector<StripedPlan> plans(rb->bins.size());
+    size_t carry_total = 0;
+    for (size_t i = 0; i < rb->bins.size(); ++i) {
+        const Bin &bin = rb->bins[i];
+        if (bin.rows_per_lane > 0) continue;
+        StripedPlan &pl = plans[i];
+        pl.sh = pick_team_shape(bin.count, bin.max_read_len, bin.max_hap_len, phmm::kStripedRowsF32);
+        const uint32_t per_wave = 64u / (uint32_t)pl.sh.lanes;
+        pl.teams = std::min<uint32_t>((bin.count + per_wave - 1) / per_wave, kStripedMaxTeams / pl.sh.waves);
+        pl.carry_at = carry_total;
+        carry_total += (phmm::team_carry_values(pl.teams, pl.sh.waves, bin.max_hap_len + 1, pl.sh.lanes) + 63) & ~size_t(63);
+    }
+    HIP_TRY(rb->carry32.alloc(carry_total));
     int nth = 0;
-    for (const Bin &bin : rb->bins) {
+    for (size_t i = 0; i < rb->bins.size(); ++i) {
+        const Bin &bin = rb->bins[i];
         const int lane = fan_out ? nth++ % (phmm_context::kSideStreams + 1) : 0;
         hipStream_t stream = lane == 0 ? c->stream : c->side[lane - 1];
         phmm::KernelArgs a{};
@@ -671,13 +699,15 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.ph2pr = c->ph2pr_f32.p;
         a.mm_table = c->mm_f32.p;
         a.out_raw = rb->raw32.p;
-        a.rescue_list = rb->rescue_list.p;
-        a.rescue_count = rb->rescue_count.p;
+        // underflowed pairs go to the queue of the bin's size range (queue 0 starts at 0, a striped range at its own first)
+        a.rescue_list = rb->rescue_list.p + (bin.queue == 0 ? 0 : bin.first);
+        a.rescue_count = rb->rescue_count.p + bin.queue;
         if (bin.rows_per_lane > 0) {
             // Few pairs: one pair per wave.  Four per wave would occupy count / 4 of the chip's 1024 SIMDs with one slow wave
             // each; 64 lanes per pair makes the sweep of a pair about half as long (a quarter of the rows per lane, 48 more
-            // steps) at 1.8x the instructions, which is free while SIMDs idle.  Measured: a 432-pair region 85 -> 46 us, 1728 pairs 86 -> 68 us, no gain from 4000 pairs on, and a loss when
-            // several submissions share the chip, hence the low threshold.
+            // steps) at 1.8x the instructions, which is free while SIMDs idle.  Measured: a 432-pair region 85 -> 46 us, 1728
+            // pairs 86 -> 68 us, no gain from 4000 pairs on, and a loss when several submissions share the chip, hence the
+            // low threshold.
             int lanes = bin.count <= kWideMaxPairs ? 64 : 16;
             if (const char *f = getenv("PHMM_FORCE_LANES")) {  // tests
                 const int l = atoi(f);
@@ -687,12 +717,9 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
             HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream));
         }
         else {
-            const TeamShape sh = pick_team_shape(bin.count, bin.max_read_len, bin.max_hap_len, phmm::kStripedRowsF32);
-            const uint32_t per_wave = 64u / (uint32_t)sh.lanes;
-            const uint32_t teams = std::min<uint32_t>((bin.count + per_wave - 1) / per_wave, kStripedMaxTeams / sh.waves);
-            const uint32_t stride = bin.max_hap_len + 1;
-            HIP_TRY(rb->carry32.alloc(phmm::team_carry_values(teams, sh.waves, stride, sh.lanes)));
-            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, sh.waves, sh.lanes, a, rb->carry32.p, stride, teams, stream));
+            const StripedPlan &pl = plans[i];
+            HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, pl.sh.waves, pl.sh.lanes, a, rb->carry32.p + pl.carry_at,
+                                             bin.max_hap_len + 1, pl.teams, stream));
         }
     }
     if (fan_out) {
@@ -708,66 +735,97 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
 {
     // The fp64 re-run of the pairs the fp32 kernels queued.  Nothing comes back to the host between the two passes: the
     // team kernel reads the queue length from device memory and its workgroups stride over the queue (all of them leave
-    // at once when it is empty), so a pass is one asynchronous chain on the context's stream.
+    // at once when it is empty), so a pass is one asynchronous chain on the context's stream.  One launch per queue (the
+    // single-pass bins share queue 0; each striped size range has its own), shaped for the whole population of the queue
+    // because its length is not known on the host.
     if (rb->n_pairs == 0) return PHMM_OK;
-    hipStream_t st = c->stream;
-    // the queue length is not known on the host: shape the launch for the whole batch (few pairs -> one pair per wave)
-    // Rows per lane: more rows amortise the per-step work of a stripe better (measured rate per computed cell 1.00 : 1.12 :
-    // 1.21 for 4 : 5 : 6), but the last stripe of a read is padded to a whole stripe -- 150-base reads are 3 x 64, 2 x 80 or
-    // 2 x 96 rows.  Take the value with the least estimated time over the batch's length bins.
-    int rows = phmm::kStripedRowsF64Min;
-    TeamShape sh{16, 1};
+    struct QueuePlan
     {
+        uint32_t base = 0, cap = 0, max_read = 0, max_hap = 0;
+        int rows = phmm::kStripedRowsF64Min;
+        TeamShape sh{16, 1};
+        uint32_t teams = 0;
+        size_t carry_at = 0;
+    } q[kQueues];
+    for (const Bin &bin : rb->bins) {
+        QueuePlan &p = q[bin.queue];
+        if (p.cap == 0) p.base = bin.queue == 0 ? 0 : bin.first;
+        p.cap += bin.count;
+        p.max_read = std::max(p.max_read, bin.max_read_len);
+        p.max_hap = std::max(p.max_hap, bin.max_hap_len);
+    }
+    size_t carry_total = 0;
+    int n_active = 0;
+    for (int qi = 0; qi < kQueues; ++qi) {
+        QueuePlan &p = q[qi];
+        if (p.cap == 0) continue;
+        ++n_active;
+        // Rows per lane: more rows amortise the per-step work of a stripe better (measured rate per computed cell 1.00 :
+        // 1.12 : 1.21 for 4 : 5 : 6), but the last stripe of a read is padded to a whole stripe -- 150-base reads are
+        // 3 x 64, 2 x 80 or 2 x 96 rows.  Take the value with the least estimated time over the queue's length bins.
         static const double rate[3] = {1.00, 1.12, 1.21};
         double best = 0.0;
+        int forced = 0;
+        if (const char *f = getenv("PHMM_FORCE_F64_ROWS")) forced = atoi(f);  // tests
         for (int k = phmm::kStripedRowsF64Min; k <= phmm::kStripedRowsF64Max; ++k) {
-            const TeamShape cand = pick_team_shape((uint32_t)std::min<uint64_t>(rb->n_pairs, 0xFFFFFFFFull), rb->max_read_len,
-                                                   rb->max_hap_len, (uint32_t)k);
+            const TeamShape cand = pick_team_shape(p.cap, p.max_read, p.max_hap, (uint32_t)k);
             const uint32_t stripe = (uint32_t)(cand.lanes * k);
             double cost = 0.0;
             for (const Bin &bin : rb->bins)
-                cost += (double)bin.count * (double)(((bin.max_read_len + stripe - 1) / stripe) * stripe);
+                if (bin.queue == qi) cost += (double)bin.count * (double)(((bin.max_read_len + stripe - 1) / stripe) * stripe);
             cost /= rate[k - phmm::kStripedRowsF64Min];
-            if (k == phmm::kStripedRowsF64Min || cost < best) {
-                best = cost;
-                rows = k;
-                sh = cand;
+            if (k == phmm::kStripedRowsF64Min || cost < best || k == forced) {
+                best = k == forced ? -1.0 : cost;
+                p.rows = k;
+                p.sh = cand;
             }
         }
-        if (const char *f = getenv("PHMM_FORCE_F64_ROWS")) {  // tests
-            const int k = atoi(f);
-            if (k >= phmm::kStripedRowsF64Min && k <= phmm::kStripedRowsF64Max) {
-                rows = k;
-                sh = pick_team_shape((uint32_t)std::min<uint64_t>(rb->n_pairs, 0xFFFFFFFFull), rb->max_read_len, rb->max_hap_len,
-                                     (uint32_t)k);
-            }
+        const uint32_t per_wave = 64u / (uint32_t)p.sh.lanes;
+        p.teams = std::min<uint32_t>((p.cap + per_wave - 1) / per_wave, kRescueMaxTeams / p.sh.waves);
+        p.carry_at = carry_total;
+        carry_total += (phmm::team_carry_values(p.teams, p.sh.waves, p.max_hap + 1, p.sh.lanes) + 63) & ~size_t(63);
+    }
+    HIP_TRY(rb->carry64.alloc(carry_total));
+    const bool fan_out = n_active > 1;
+    if (fan_out) {
+        HIP_TRY(hipEventRecord(c->fork, c->stream));
+        for (int i = 0; i < phmm_context::kSideStreams; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
+    }
+    int nth = 0;
+    for (int qi = 0; qi < kQueues; ++qi) {
+        const QueuePlan &p = q[qi];
+        if (p.cap == 0) continue;
+        const int lane = fan_out ? nth++ % (phmm_context::kSideStreams + 1) : 0;
+        hipStream_t st = lane == 0 ? c->stream : c->side[lane - 1];
+        phmm::KernelArgs a{};
+        a.read_bases = rb->read_bases.p;
+        a.read_qual = rb->read_qual.p;
+        a.read_ins = rb->read_ins.p;
+        a.read_del = rb->del_aliases_ins ? rb->read_ins.p : rb->read_del.p;
+        a.read_gcp = rb->read_gcp.p;
+        a.read_off = rb->read_off.p;
+        a.read_len = rb->read_len.p;
+        a.hap_len = rb->hap_len.p;
+        a.planes = rb->planes.p;
+        a.plane_off = rb->plane_off.p;
+        a.pair_read = rb->pair_read.p;
+        a.pair_hap = rb->pair_hap.p;
+        a.order = rb->rescue_list.p + p.base;
+        a.n_pairs = 0;
+        a.n_pairs_dev = rb->rescue_count.p + qi;
+        a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(p.max_hap);
+        a.ph2pr = c->ph2pr_f64.p;
+        a.mm_table = c->mm_f64.p;
+        a.out_raw = rb->raw64.p;
+        HIP_TRY(phmm::launch_striped_f64(p.rows, rb->uniform_gcp, p.sh.waves, p.sh.lanes, a, rb->carry64.p + p.carry_at,
+                                         p.max_hap + 1, p.teams, st));
+    }
+    if (fan_out) {
+        for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+            HIP_TRY(hipEventRecord(c->join[i], c->side[i]));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->join[i], 0));
         }
     }
-    const uint32_t per_wave = 64u / (uint32_t)sh.lanes;
-    const uint32_t teams = std::min<uint32_t>((uint32_t)((rb->n_pairs + per_wave - 1) / per_wave), kRescueMaxTeams / sh.waves);
-    const uint32_t stride = rb->max_hap_len + 1;
-    HIP_TRY(rb->carry64.alloc(phmm::team_carry_values(teams, sh.waves, stride, sh.lanes)));
-    phmm::KernelArgs a{};
-    a.read_bases = rb->read_bases.p;
-    a.read_qual = rb->read_qual.p;
-    a.read_ins = rb->read_ins.p;
-    a.read_del = rb->del_aliases_ins ? rb->read_ins.p : rb->read_del.p;
-    a.read_gcp = rb->read_gcp.p;
-    a.read_off = rb->read_off.p;
-    a.read_len = rb->read_len.p;
-    a.hap_len = rb->hap_len.p;
-    a.planes = rb->planes.p;
-    a.plane_off = rb->plane_off.p;
-    a.pair_read = rb->pair_read.p;
-    a.pair_hap = rb->pair_hap.p;
-    a.order = rb->rescue_list.p;
-    a.n_pairs = 0;
-    a.n_pairs_dev = rb->rescue_count.p;
-    a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(rb->max_hap_len);
-    a.ph2pr = c->ph2pr_f64.p;
-    a.mm_table = c->mm_f64.p;
-    a.out_raw = rb->raw64.p;
-    HIP_TRY(phmm::launch_striped_f64(rows, rb->uniform_gcp, sh.waves, sh.lanes, a, rb->carry64.p, stride, teams, st));
     return PHMM_OK;
 }
 
@@ -821,15 +879,19 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
     if (n) {
         HIP_TRY(rb->out_stage.ensure(off64 + n * sizeof(double)));
         if (want)
-            HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, off_cnt + sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, off_cnt + kQueues * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         else
-            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off_cnt, rb->rescue_count.p, sizeof(uint32_t),
+            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off_cnt, rb->rescue_count.p, kQueues * sizeof(uint32_t),
                                    hipMemcpyDeviceToHost, c->stream));
     }
     PHASE(4);
     HIP_TRY(hipStreamSynchronize(c->stream));  // (polling hipStreamQuery instead gains nothing: measured)
     PHASE(5);
-    if (n) rb->last_rescued = *reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(rb->out_stage.p) + off_cnt);
+    if (n) {
+        const uint32_t *counts = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(rb->out_stage.p) + off_cnt);
+        rb->last_rescued = 0;
+        for (int qi = 0; qi < kQueues; ++qi) rb->last_rescued += counts[qi];
+    }
     const bool want64 = out_log10 && rb->last_rescued && n;
     if (want64) {
         HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off64, rb->raw64.p, n * sizeof(double),

@@ -67,6 +67,7 @@ inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t car
 }
 // batch set-up (one launch): optional device-side read preparation, haplotype bit planes, rescue queue reset
 constexpr int kSetupThreads = 128;
+constexpr int kRescueQueues = 5;  // rescue queues per batch: the single-pass bins share one, each striped size range has one
 struct SetupArgs
 {
     // haplotype planes
@@ -82,7 +83,7 @@ struct SetupArgs
     uint32_t n_prep_reads;
     int32_t min_q, pcr_model;
     uint8_t gap_open, gap_cont;
-    uint32_t *rescue_count;  // zeroed if non-null
+    uint32_t *rescue_count;  // kRescueQueues counters, zeroed if non-null
 };
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s);
 

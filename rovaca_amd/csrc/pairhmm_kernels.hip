@@ -903,7 +903,7 @@ hipError_t launch_striped_f64(int rows_per_lane, bool uniform_gcp, int waves_per
 // the way.  A region-sized call is a chain of dependent launches and copies, each worth 5-10 us: fewer links, lower latency.
 __global__ void __launch_bounds__(kSetupThreads) setup_kernel(SetupArgs s)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && s.rescue_count) *s.rescue_count = 0;
+    if (blockIdx.x == 0 && threadIdx.x < kRescueQueues && s.rescue_count) s.rescue_count[threadIdx.x] = 0;
     if (blockIdx.x < s.n_prep_reads) {
         prep_one_read(s.read_bases, s.read_qual, s.read_gop, s.read_gcp, s.read_off, s.read_len, s.read_mapq, s.min_q, s.pcr_model,
                       s.gap_open, s.gap_cont, blockIdx.x);
