@@ -12,7 +12,10 @@ constexpr int kBlockThreads = 256;    // 4 waves = 16 pairs per workgroup
 constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take the single-pass kernel
 constexpr int kMaxRowsPerLaneWide = 4;  // same limit for the one-pair-per-wave shape: 64 * 4 rows
 constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other
-constexpr int kStripedRowsF32 = 8;   // rows per lane of the striped fp32 kernel (stripes of 256 read rows)
+#ifndef PHMM_STRIPED_ROWS_F32
+#define PHMM_STRIPED_ROWS_F32 8
+#endif
+constexpr int kStripedRowsF32 = PHMM_STRIPED_ROWS_F32;   // rows per lane of the striped fp32 kernel (stripes of 256 read rows)
 // rows per lane of the striped fp64 kernel: instantiated for 4, 5 and 6 (stripes of 64, 80, 96 read rows with 16 lanes per
 // pair); the launch picks the one that wastes the fewest padding rows on the batch's read lengths
 constexpr int kStripedRowsF64Min = 4, kStripedRowsF64Max = 6;

@@ -248,14 +248,17 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
     // ---- the sweep ----
     const uint32_t Tg = valid ? H + (G - 1) : 0;  // last step of this group
     uint32_t Tmax = Tg;                           // wave-uniform loop bound
-    uint32_t Tmin = Tg;                           // until here every lane of the wave is busy once the pipeline is full
     if (G == 16) {
         Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
         Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+    }
+    Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
+
+    uint32_t Tmin = Tg;  // until here every lane of the wave is busy once the pipeline is full
+    if (G == 16) {
         Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
         Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
     }
-    Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
     Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
 
     uint32_t mask[K];
@@ -386,7 +389,10 @@ template <int G> constexpr uint32_t team_lag() { return G == 64 ? 6u : 4u; }
 // G = lanes per pair: 16 (four pairs per wave, DPP row_shr) or 64 (one pair per wave, DPP wave_shr -- for batches with
 // so few pairs that four-per-wave would leave the chip empty: one long-read pair then keeps up to WP waves busy)
 template <typename T, int K, bool UG, int WP, int G>
-__global__ void __launch_bounds__(64 * WP, 2) pairhmm_team_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
+#ifndef PHMM_TEAM_WAVES_F32
+#define PHMM_TEAM_WAVES_F32 2
+#endif
+__global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 : 2) pairhmm_team_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
 {
     extern __shared__ uint32_t lds[];
     constexpr int S = G * K;

@@ -5,7 +5,7 @@ import sys
 text = open(sys.argv[1]).read()
 ks = [int(x) for x in sys.argv[2].split(",")]
 for K in ks:
-    m = re.search(r"^_ZN4phmm23pairhmm_systolic_kernelIfLi%dELb1EEEvNS_10KernelArgsE:.*?s_endpgm" % K, text, re.S | re.M)
+    m = re.search(r"^_ZN4phmm23pairhmm_systolic_kernelIfLi%dELb1ELi16EEEvNS_10KernelArgsE:.*?s_endpgm" % K, text, re.S | re.M)
     lines = m.group(0).split("\n")
     hdr = [i for i, l in enumerate(lines) if "Loop Header" in l]
     best = None
