@@ -1,0 +1,68 @@
+"""Turn gpurun_out/prof (tools/profile_round.sh) into the committed summaries under profiles/: per-config kernel stats,
+the PMC summary of the headline kernel and profiles/hbm_traffic.json (read by bench.py for roofline.traffic)."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1_final"
+dst = os.path.join(ROOT, "profiles")
+
+stats = {}
+for c in ("c2", "c3", "c5"):
+    f = os.path.join(src, "trace_" + c, c + "_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, c)))
+        stats[c] = list(csv.DictReader(open(f)))
+
+hot = next(r for r in stats["c2"] if "pairhmm_systolic_kernel" in r["Name"])
+bench_ms = None
+m = re.search(r'"kernel_ms": ([0-9.]+)', open(os.path.join(src, "bench_c2.log")).read())
+if m:
+    bench_ms = float(m.group(1))
+
+counters = {}
+for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "pairhmm_systolic_kernel" not in r["Kernel_Name"]:
+            continue
+        counters.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+        counters[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+mean = {k: sum(v.values()) / len(v) for k, v in counters.items()}
+avg_ms = float(hot["AverageNs"]) / 1e6
+lines = [
+    "rocprofv3 --pmc passes (separate runs, one counter group each; tools/profile_round.sh) of",
+    "`python3 bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline` on MI355X.",
+    "kernel: %s (config c2: 1,000,000 pairs, 150 x 300)" % hot["Name"],
+    "FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x",
+    "(MI355X_MICROARCH.md, HBM section), so HBM read bytes are bracketed by [1x, 2x] FETCH_SIZE * 1024.",
+    "kernel-trace average duration of the same kernel (profiles/%s_c2_kernel_stats.csv): %.4f ms (min %.4f); bench.py HIP events in that run: %s ms"
+    % (tag, avg_ms, float(hot["MinNs"]) / 1e6, bench_ms),
+    "",
+]
+for k in sorted(mean):
+    lines.append("%-24s launches=%d mean_per_launch=%g" % (k, len(counters[k]), mean[k]))
+if "SQ_INSTS_VALU" in mean and "SQ_WAVES" in mean:
+    per_wave = mean["SQ_INSTS_VALU"] / mean["SQ_WAVES"]
+    lines += ["", "derived: VALU wave-instructions per launch %.3g; per wave %.0f; per sweep step (315 steps/pair) %.1f"
+              % (mean["SQ_INSTS_VALU"], per_wave, per_wave / 315.0)]
+    # 1024 SIMDs; cycles available per SIMD = duration * clock
+    for ghz in (2.05,):
+        lines.append("         cycles per VALU instruction per SIMD at %.2f GHz over %.3f ms: %.2f"
+                     % (ghz, avg_ms, avg_ms * 1e-3 * ghz * 1e9 * 1024 / mean["SQ_INSTS_VALU"]))
+open(os.path.join(dst, "%s_c2_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
+if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+    fetch, write = mean["FETCH_SIZE"] * 1024, mean["WRITE_SIZE"] * 1024
+    json.dump({"c2": int(2 * fetch + write),
+               "_note": "bytes per launch of %s on config c2: 2 x FETCH_SIZE (gfx950 correction, upper bound) + WRITE_SIZE, "
+                        "from profiles/%s_c2_pmc_summary.txt" % (hot["Name"].replace("void ", "").split("(")[0], tag),
+               "c2_fetch_raw_bytes": int(fetch), "c2_write_bytes": int(write)},
+              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
+for c in stats:
+    print(c, [(r["Name"][:60], r["Calls"], r["AverageNs"]) for r in stats[c][:4]])
