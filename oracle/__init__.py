@@ -171,3 +171,91 @@ def ref_regions_16x1(b, n_threads=1):
                              b.hap_bases, b.hap_off, b.hap_len, b.region_read, b.region_hap, b.region_pair,
                              len(b.region_read) - 1, raw, n_threads)
     return raw, sec
+
+
+# ------------------------------------------------------------------------------------------------
+# Smith-Waterman: restatement (oracle/sw_oracle.c) and the reference's own sw_avx.c / sw_avx2.c
+# ------------------------------------------------------------------------------------------------
+SW_PARAMS_ASSEMBLE = (200, -150, -260, -11)  # sw_avx.c:13
+SW_PARAMS_GENOTYPE = (10, -15, -30, -5)      # sw_avx.c:14
+SW_MAX_SEQ_LEN = 2048                        # sw_avx.c:17
+_SW_LIB = None
+_SW_REF = None
+_SW_REF_TRIED = False
+
+
+class SwResult(C.Structure):
+    _fields_ = [("score", C.c_int32), ("max_i", C.c_int16), ("max_j", C.c_int16), ("alignment_offset", C.c_int16),
+                ("too_long", C.c_int16), ("cigar_count", C.c_uint32)]
+
+
+def sw_lib():
+    global _SW_LIB
+    if _SW_LIB is None:
+        path = os.path.join(_HERE, "_build", "libsw_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.sw_oracle_align.argtypes = [u8p, C.c_int32, u8p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(SwResult),
+                                      u32p, C.c_uint32]
+        L.sw_oracle_align.restype = C.c_int
+        _SW_LIB = L
+    return _SW_LIB
+
+
+def sw_ref():
+    """The reference's own Smith-Waterman (oracle/_ref/libsw_ref.so) or None."""
+    global _SW_REF, _SW_REF_TRIED
+    if _SW_REF_TRIED:
+        return _SW_REF
+    _SW_REF_TRIED = True
+    path = os.path.join(_HERE, "_ref", "libsw_ref.so")
+    if not os.path.exists(path) or not cpu_has_avx512():
+        return None
+    L = C.CDLL(path)
+    i32 = C.POINTER(C.c_int32)
+    L.ref_sw_align.argtypes = [C.c_int, C.c_int, u8p, C.c_int32, u8p, C.c_int32, i32, i32, i32, i32, u32p, C.c_uint32,
+                               C.POINTER(C.c_uint32)]
+    L.ref_sw_align.restype = C.c_int
+    L.ref_sw_params.argtypes = [C.c_int, i32]
+    L.ref_sw_params.restype = C.c_int
+    _SW_REF = L
+    return L
+
+
+def _as_u8(s):
+    return np.ascontiguousarray(np.frombuffer(s, np.uint8) if isinstance(s, (bytes, bytearray)) else s, np.uint8)
+
+
+def sw_align(seq1, seq2, params=SW_PARAMS_GENOTYPE, max_seq_len=SW_MAX_SEQ_LEN):
+    """-> dict(score, max_i, max_j, alignment_offset, too_long, cigar=[u32 BAM elements]) from the restatement."""
+    a, b = _as_u8(seq1), _as_u8(seq2)
+    cap = len(a) + len(b) + 8
+    cig = np.zeros(cap, np.uint32)
+    res = SwResult()
+    p = (C.c_int32 * 4)(*params)
+    rc = sw_lib().sw_oracle_align(a if len(a) else np.zeros(1, np.uint8), len(a), b if len(b) else np.zeros(1, np.uint8),
+                                  len(b), p, max_seq_len, C.byref(res), cig, cap)
+    if rc != 0:
+        raise ValueError("sw_oracle_align failed: %d" % rc)
+    return dict(score=res.score, max_i=res.max_i, max_j=res.max_j, alignment_offset=res.alignment_offset,
+                too_long=bool(res.too_long), cigar=cig[:res.cigar_count].copy())
+
+
+def ref_sw_align(seq1, seq2, is_assemble=False, which=0):
+    """The same through the reference's object code (which: 0 as selected by sw_avx_init, 1 AVX-512, 2 AVX2)."""
+    L = sw_ref()
+    a, b = _as_u8(seq1), _as_u8(seq2)
+    cap = len(a) + len(b) + 8
+    cig = np.zeros(cap, np.uint32)
+    sc, mi, mj, off = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    cnt = C.c_uint32()
+    rc = L.ref_sw_align(int(is_assemble), which, a, len(a), b, len(b), C.byref(sc), C.byref(mi), C.byref(mj), C.byref(off),
+                        cig, cap, C.byref(cnt))
+    if rc != 0:
+        raise ValueError("ref_sw_align failed: %d" % rc)
+    return dict(score=sc.value, max_i=mi.value, max_j=mj.value, alignment_offset=off.value, cigar=cig[:cnt.value].copy())
+
+
+def cigar_string(cigar):
+    return "".join("%d%s" % (int(c) >> 4, "MIDNSHP=XB"[int(c) & 15]) for c in cigar)
