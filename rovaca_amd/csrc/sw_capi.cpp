@@ -1,0 +1,314 @@
+// sw_capi.cpp -- the C ABI of include/smithwaterman_hip.h: host side of the MI355X Smith-Waterman aligner.
+// There is no CPU fallback here: without a GPU swhip_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/smithwaterman_hip.h"
+#include "sw_device.h"
+
+static_assert(sizeof(swhip_alignment) == sizeof(swhip::Alignment), "device and ABI result structs must agree");
+
+namespace
+{
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(SWHIP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// grow-only device buffer
+struct DevBytes
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    ~DevBytes()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+};
+
+struct HostBytes
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    ~HostBytes()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+};
+
+}  // namespace
+
+struct swhip_context
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBytes blob, bt, scratch, out, cigars;
+    HostBytes stage, back;
+};
+
+extern "C" {
+
+int swhip_abi_version(void) { return SWHIP_ABI_VERSION; }
+const char *swhip_last_error(void) { return g_err; }
+
+int swhip_create(int device_id, void *stream, swhip_context **out)
+{
+    if (!out || device_id < 0) return fail(SWHIP_E_INVALID, "swhip_create: bad arguments");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SWHIP_E_NO_DEVICE, "swhip_create: no HIP device visible (this aligner has no CPU fallback)");
+    if (device_id >= n) return fail(SWHIP_E_NO_DEVICE, "swhip_create: device %d of %d does not exist", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    swhip_context *c = new (std::nothrow) swhip_context();
+    if (!c) return fail(SWHIP_E_NOMEM, "swhip_create: out of host memory");
+    c->device = device_id;
+    hipError_t e = hipSuccess;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    }
+    else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        c->own_stream = e == hipSuccess;
+    }
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        swhip_destroy(c);
+        return fail(SWHIP_E_HIP, "swhip_create: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return SWHIP_OK;
+}
+
+void swhip_destroy(swhip_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch *b, swhip_alignment *out, uint32_t *cigars,
+                uint64_t cigar_capacity, uint64_t *cigars_used, swhip_stats *stats)
+{
+    if (!c || !params || !b || (b->n_pairs && (!out || !cigars_used)))
+        return fail(SWHIP_E_INVALID, "swhip_align: null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t n = b->n_pairs;
+    if (cigars_used) *cigars_used = 0;
+    if (stats) *stats = swhip_stats{};
+    if (n == 0) return SWHIP_OK;
+    if (n > 0xFFFFFFF0ull) return fail(SWHIP_E_INVALID, "swhip_align: more than 2^32 alignments in one batch");
+    if (!b->ref_bases || !b->ref_off || !b->ref_len || !b->seq_bases || !b->seq_off || !b->seq_len || !b->pair_ref || !b->pair_seq)
+        return fail(SWHIP_E_INVALID, "swhip_align: null table pointer");
+    HIP_TRY(hipSetDevice(c->device));
+
+    // ---- validate, find extents ----
+    uint64_t ref_bytes = 0, seq_bytes = 0;
+    for (uint32_t r = 0; r < b->n_refs; ++r) {
+        if (b->ref_len[r] == 0) return fail(SWHIP_E_INVALID, "swhip_align: reference sequence %u is empty", r);
+        ref_bytes = std::max<uint64_t>(ref_bytes, (uint64_t)b->ref_off[r] + b->ref_len[r]);
+    }
+    for (uint32_t s = 0; s < b->n_seqs; ++s) {
+        if (b->seq_len[s] == 0) return fail(SWHIP_E_INVALID, "swhip_align: sequence %u is empty", s);
+        seq_bytes = std::max<uint64_t>(seq_bytes, (uint64_t)b->seq_off[s] + b->seq_len[s]);
+    }
+
+    // ---- classify: (lanes per alignment, columns per lane); longest reference first inside a launch ----
+    std::vector<uint64_t> keys;  // class << 48 | (0xFFFF - len1) << 32 | pair
+    keys.reserve(n);
+    uint64_t cells = 0, worst_elems = 0;
+    for (uint64_t p = 0; p < n; ++p) {
+        const uint32_t r = b->pair_ref[p], s = b->pair_seq[p];
+        if (r >= b->n_refs || s >= b->n_seqs)
+            return fail(SWHIP_E_INVALID, "swhip_align: alignment %llu indexes outside the tables", (unsigned long long)p);
+        const uint32_t l1 = b->ref_len[r], l2 = b->seq_len[s];
+        if (std::max(l1, l2) >= (uint32_t)swhip::kMaxSeqLen) {  // sw_avx.c:490-495
+            out[p] = swhip_alignment{};
+            out[p].alignment_offset = 1;
+            out[p].too_long = 1;
+            continue;
+        }
+        const int lanes = l2 <= 16u * swhip::kMaxColsPerLaneNarrow ? 16 : 64;
+        const int k = swhip::pick_cols_per_lane(l2, lanes);
+        const uint64_t cls = (uint64_t)(lanes == 16 ? 0 : 64) + (uint64_t)k;
+        keys.push_back((cls << 48) | ((uint64_t)(0xFFFFu - l1) << 32) | p);
+        cells += (uint64_t)l1 * l2;
+        worst_elems += (uint64_t)l1 + l2 + 2;
+    }
+    std::sort(keys.begin(), keys.end());
+    const uint64_t m = keys.size();
+    if (stats) stats->cells = cells;
+    if (m == 0) return SWHIP_OK;
+
+    // ---- per-pair device offsets ----
+    std::vector<uint32_t> order(m);
+    std::vector<uint64_t> bt_off(n, 0), scr_off(n, 0);
+    uint64_t bt_words = 0, scr_slots = 0;
+    struct Launch
+    {
+        int lanes, k;
+        uint32_t first, count;
+    };
+    std::vector<Launch> launches;
+    for (uint64_t i = 0; i < m; ++i) {
+        const uint32_t p = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+        const uint64_t cls = keys[i] >> 48;
+        const int lanes = cls >= 64 ? 64 : 16, k = (int)(cls >= 64 ? cls - 64 : cls);
+        order[i] = p;
+        if (launches.empty() || launches.back().lanes != lanes || launches.back().k != k)
+            launches.push_back(Launch{lanes, k, (uint32_t)i, 0});
+        launches.back().count++;
+        const uint32_t l1 = b->ref_len[b->pair_ref[p]], l2 = b->seq_len[b->pair_seq[p]];
+        bt_off[p] = bt_words;
+        bt_words += (uint64_t)(l1 + lanes - 1) * lanes * swhip::bt_words(k);
+        scr_off[p] = scr_slots;
+        scr_slots += swhip::scratch_slots(l1, l2, k);
+    }
+
+    // ---- upload: one pinned stage, one copy ----
+    hipStream_t st = c->stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) {
+        const size_t at = total;
+        total += (bytes + 255) & ~size_t(255);
+        return at;
+    };
+    const size_t o_ref = reserve(ref_bytes), o_roff = reserve(b->n_refs * 4ull), o_rlen = reserve(b->n_refs * 4ull);
+    const size_t o_seq = reserve(seq_bytes), o_soff = reserve(b->n_seqs * 4ull), o_slen = reserve(b->n_seqs * 4ull);
+    const size_t o_pr = reserve(n * 4), o_ps = reserve(n * 4), o_order = reserve(m * 4);
+    const size_t o_bt = reserve(n * 8), o_scr = reserve(n * 8), o_cur = reserve(4);
+    HIP_TRY(c->stage.ensure(total));
+    HIP_TRY(c->blob.ensure(total));
+    uint8_t *sp = static_cast<uint8_t *>(c->stage.p);
+    memcpy(sp + o_ref, b->ref_bases, ref_bytes);
+    memcpy(sp + o_roff, b->ref_off, b->n_refs * 4ull);
+    memcpy(sp + o_rlen, b->ref_len, b->n_refs * 4ull);
+    memcpy(sp + o_seq, b->seq_bases, seq_bytes);
+    memcpy(sp + o_soff, b->seq_off, b->n_seqs * 4ull);
+    memcpy(sp + o_slen, b->seq_len, b->n_seqs * 4ull);
+    memcpy(sp + o_pr, b->pair_ref, n * 4);
+    memcpy(sp + o_ps, b->pair_seq, n * 4);
+    memcpy(sp + o_order, order.data(), m * 4);
+    memcpy(sp + o_bt, bt_off.data(), n * 8);
+    memcpy(sp + o_scr, scr_off.data(), n * 8);
+    memset(sp + o_cur, 0, 4);
+    HIP_TRY(hipMemcpyAsync(c->blob.p, c->stage.p, total, hipMemcpyHostToDevice, st));
+    HIP_TRY(c->bt.ensure(bt_words * 4));
+    HIP_TRY(c->scratch.ensure(scr_slots * 4));
+    HIP_TRY(c->out.ensure(n * sizeof(swhip::Alignment)));
+    HIP_TRY(c->cigars.ensure(worst_elems * 4));
+
+    uint8_t *base = static_cast<uint8_t *>(c->blob.p);
+    swhip::SwArgs a{};
+    a.ref_bases = base + o_ref;
+    a.ref_off = reinterpret_cast<const uint32_t *>(base + o_roff);
+    a.ref_len = reinterpret_cast<const uint32_t *>(base + o_rlen);
+    a.seq_bases = base + o_seq;
+    a.seq_off = reinterpret_cast<const uint32_t *>(base + o_soff);
+    a.seq_len = reinterpret_cast<const uint32_t *>(base + o_slen);
+    a.pair_ref = reinterpret_cast<const uint32_t *>(base + o_pr);
+    a.pair_seq = reinterpret_cast<const uint32_t *>(base + o_ps);
+    a.w_match = params->match;
+    a.w_mismatch = params->mismatch;
+    a.w_open = params->gap_open;
+    a.w_extend = params->gap_extend;
+    a.bt = static_cast<uint32_t *>(c->bt.p);
+    a.bt_off = reinterpret_cast<const uint64_t *>(base + o_bt);
+    a.scratch = static_cast<int32_t *>(c->scratch.p);
+    a.scratch_off = reinterpret_cast<const uint64_t *>(base + o_scr);
+    a.out = static_cast<swhip::Alignment *>(c->out.p);
+    a.cigars = static_cast<uint32_t *>(c->cigars.p);
+    a.cigar_cursor = reinterpret_cast<uint32_t *>(base + o_cur);
+
+    HIP_TRY(hipEventRecord(c->ev0, st));
+    for (const Launch &l : launches) {
+        a.order = reinterpret_cast<const uint32_t *>(base + o_order) + l.first;
+        a.n_pairs = l.count;
+        HIP_TRY(swhip::launch_sw(l.k, l.lanes, a, st));
+    }
+    HIP_TRY(hipEventRecord(c->ev1, st));
+
+    // ---- download: results + the element count, then the elements ----
+    const size_t res_bytes = n * sizeof(swhip::Alignment);
+    const size_t b_cur = (res_bytes + 255) & ~size_t(255);
+    HIP_TRY(c->back.ensure(b_cur + 256 + worst_elems * 4));
+    uint8_t *bp = static_cast<uint8_t *>(c->back.p);
+    HIP_TRY(hipMemcpyAsync(bp, c->out.p, res_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(bp + b_cur, a.cigar_cursor, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t used = *reinterpret_cast<const uint32_t *>(bp + b_cur);
+    const swhip_alignment *dev_res = reinterpret_cast<const swhip_alignment *>(bp);
+    for (uint64_t i = 0; i < m; ++i) {
+        const uint32_t p = order[i];
+        out[p] = dev_res[p];
+    }
+    *cigars_used = used;
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        stats->kernel_ms = ms;
+        stats->n_launches = (uint32_t)launches.size();
+    }
+    if (used > cigar_capacity) return fail(SWHIP_E_CAPACITY, "swhip_align: %u CIGAR elements, room for %llu", used, (unsigned long long)cigar_capacity);
+    if (used) {
+        if (!cigars) return fail(SWHIP_E_INVALID, "swhip_align: null cigars buffer");
+        HIP_TRY(hipMemcpyAsync(bp + b_cur + 256, c->cigars.p, (size_t)used * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        memcpy(cigars, bp + b_cur + 256, (size_t)used * 4);
+    }
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SWHIP_OK;
+}
+
+}  // extern "C"

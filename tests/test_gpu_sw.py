@@ -1,0 +1,120 @@
+"""Smith-Waterman on the MI355X through the C ABI, bit for bit against the golden vectors generated from
+the reference's sw_avx.c and against the CPU restatement on seeded batches."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from rovaca_amd import swapi
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "sw_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def aligner():
+    a = swapi.Aligner(0)
+    yield a
+    a.close()
+
+
+def _check(aligner, refs, seqs, pairs, params):
+    out, cig, st = aligner.align(refs, seqs, pairs, params)
+    for p, (r, s) in enumerate(pairs):
+        o = oracle.sw_align(refs[r], seqs[s], params)
+        row = out[p]
+        if o["too_long"]:
+            assert row["too_long"] == 1 and row["alignment_offset"] == 1 and row["cigar_count"] == 0
+            continue
+        got = (int(row["score"]), int(row["max_i"]), int(row["max_j"]), int(row["alignment_offset"]))
+        assert got == (o["score"], o["max_i"], o["max_j"], o["alignment_offset"]), (p, len(refs[r]), len(seqs[s]), got, o)
+        assert np.array_equal(swapi.cigar_of(row, cig), o["cigar"]), (p, oracle.cigar_string(swapi.cigar_of(row, cig)),
+                                                                      oracle.cigar_string(o["cigar"]))
+    return out, cig, st
+
+
+@pytest.mark.parametrize("tag", ["genotype", "assemble"])
+def test_golden_vectors_bit_exact(aligner, tag):
+    g = np.load(GOLD)
+    params = tuple(int(x) for x in g["params"][0 if tag == "genotype" else 1])
+    n = len(g["len1"])
+    refs = [g["seq1"][g["off1"][k]:g["off1"][k] + g["len1"][k]] for k in range(n)]
+    seqs = [g["seq2"][g["off2"][k]:g["off2"][k] + g["len2"][k]] for k in range(n)]
+    out, cig, _ = aligner.align(refs, seqs, [(k, k) for k in range(n)], params)
+    res, gc, coff = g[tag + "_result"], g[tag + "_cigar"], g[tag + "_cigar_off"]
+    for k in range(n):
+        if res[k][4]:
+            assert out[k]["too_long"] == 1 and out[k]["alignment_offset"] == 1 and out[k]["cigar_count"] == 0
+            continue
+        got = (int(out[k]["score"]), int(out[k]["max_i"]), int(out[k]["max_j"]), int(out[k]["alignment_offset"]))
+        assert got == tuple(int(x) for x in res[k][:4]), (k, got, res[k])
+        assert np.array_equal(swapi.cigar_of(out[k], cig), gc[coff[k]:coff[k + 1]]), k
+
+
+def test_region_shaped_batch_reads_vs_best_haplotype(aligner):
+    # the genotyping call site: every read of a region against its best haplotype (alignment_utils.cpp:572-579)
+    rng = np.random.default_rng(7)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    refs, seqs, pairs = [], [], []
+    for region in range(12):
+        base = acgt[rng.integers(0, 4, int(rng.integers(250, 450)))]
+        haps = []
+        for h in range(5):
+            hap = base.copy()
+            for _ in range(h):
+                hap[int(rng.integers(0, len(hap)))] = acgt[rng.integers(0, 4)]
+            haps.append(hap)
+        h0 = len(refs)
+        refs += haps
+        for r in range(30):
+            hap = haps[int(rng.integers(0, 5))]
+            n = int(rng.integers(30, 151))
+            a = int(rng.integers(0, len(hap) - n))
+            read = hap[a:a + n].copy()
+            read[rng.random(n) < 0.01] = ord("A")
+            if r % 5 == 0:
+                k = int(rng.integers(1, n - 1))
+                read = np.concatenate([read[:k], acgt[rng.integers(0, 4, int(rng.integers(1, 9)))], read[k:]])
+            if r % 7 == 0:
+                k = int(rng.integers(1, len(read) - 10))
+                read = np.concatenate([read[:k], read[k + int(rng.integers(1, 6)):]])
+            seqs.append(read)
+            pairs.append((h0 + int(rng.integers(0, 5)), len(seqs) - 1))
+    _check(aligner, refs, seqs, pairs, swapi.PARAMS_GENOTYPE)
+
+
+def test_every_geometry_and_long_sequences(aligner):
+    # seq2 lengths across every columns-per-lane instantiation of both shapes (16 and 64 lanes per alignment)
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    refs, seqs, pairs = [], [], []
+    for n2 in [1, 2, 3, 31, 32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 193, 224, 225, 255, 256, 257, 300, 511, 512, 513,
+               700, 1023, 1024, 1025, 1500, 2047]:
+        n1 = int(rng.integers(max(1, n2 // 2), min(2047, 2 * n2 + 40) + 1))
+        ref = acgt[rng.integers(0, 4, n1)]
+        if n2 <= n1:
+            a = int(rng.integers(0, n1 - n2 + 1))
+            seq = ref[a:a + n2].copy()
+            seq[rng.random(n2) < 0.03] = ord("T")
+        else:
+            seq = np.concatenate([ref, acgt[rng.integers(0, 4, n2 - n1)]])
+        refs.append(ref)
+        seqs.append(seq)
+        pairs.append((len(refs) - 1, len(seqs) - 1))
+    for params in (swapi.PARAMS_GENOTYPE, swapi.PARAMS_ASSEMBLE):
+        _check(aligner, refs, seqs, pairs, params)
+
+
+def test_too_long_and_invalid(aligner):
+    rng = np.random.default_rng(10)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    big = acgt[rng.integers(0, 4, 2048)]
+    out, cig, _ = _check(aligner, [big, big[:100]], [big[:50], big], [(0, 0), (1, 1), (1, 0)], swapi.PARAMS_GENOTYPE)
+    assert out[0]["too_long"] == 1 and out[1]["too_long"] == 1 and out[2]["too_long"] == 0
+    with pytest.raises(RuntimeError):
+        aligner.align([b"ACGT"], [b""], [(0, 0)])
+    with pytest.raises(RuntimeError):
+        aligner.align([b"ACGT"], [b"AC"], [(0, 1)])
+    out, cig, _ = aligner.align([], [], [])
+    assert len(out) == 0 and len(cig) == 0
