@@ -219,6 +219,8 @@ def sw_ref():
     L.ref_sw_align.restype = C.c_int
     L.ref_sw_params.argtypes = [C.c_int, i32]
     L.ref_sw_params.restype = C.c_int
+    L.ref_sw_batch.argtypes = [C.c_int, u8p, u32p, u32p, u8p, u32p, u32p, u32p, u32p, C.c_uint64, C.c_int, C.POINTER(C.c_int64)]
+    L.ref_sw_batch.restype = C.c_double
     _SW_REF = L
     return L
 

@@ -56,3 +56,30 @@ int ref_sw_params(int is_assemble, int32_t out[4])
     out[3] = g_handle[is_assemble]->para.gap_extend;
     return 0;
 }
+
+/* time `reps` passes over n alignments on the calling thread; returns seconds.  Used by tools/bench_sw.py for the CPU baseline. */
+#include <time.h>
+double ref_sw_batch(int is_assemble, const uint8_t *ref_bases, const uint32_t *ref_off, const uint32_t *ref_len,
+                    const uint8_t *seq_bases, const uint32_t *seq_off, const uint32_t *seq_len, const uint32_t *pair_ref,
+                    const uint32_t *pair_seq, uint64_t n, int reps, int64_t *checksum)
+{
+    is_assemble = is_assemble ? 1 : 0;
+    if (!g_handle[is_assemble]) g_handle[is_assemble] = sw_avx_init((uint8_t)is_assemble);
+    p_lib_sw_avx p = g_handle[is_assemble];
+    struct timespec t0, t1;
+    int64_t sum = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int rep = 0; rep < reps; ++rep)
+        for (uint64_t k = 0; k < n; ++k) {
+            const uint32_t r = pair_ref[k], s = pair_seq[k];
+            memcpy(p->seq1, ref_bases + ref_off[r], ref_len[r]);
+            memcpy(p->seq2, seq_bases + seq_off[s], seq_len[s]);
+            p->len1 = (int16_t)ref_len[r];
+            p->len2 = (int16_t)seq_len[s];
+            p->avx_function(p);
+            sum += p->score + p->alignment_offset + (int64_t)p->cigar_count;
+        }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (checksum) *checksum = sum;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

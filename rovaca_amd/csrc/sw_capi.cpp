@@ -197,7 +197,7 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     struct Launch
     {
         int lanes, k;
-        uint32_t first, count;
+        uint32_t first, count, max_len1;
     };
     std::vector<Launch> launches;
     for (uint64_t i = 0; i < m; ++i) {
@@ -206,9 +206,10 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
         const int lanes = cls >= 64 ? 64 : 16, k = (int)(cls >= 64 ? cls - 64 : cls);
         order[i] = p;
         if (launches.empty() || launches.back().lanes != lanes || launches.back().k != k)
-            launches.push_back(Launch{lanes, k, (uint32_t)i, 0});
+            launches.push_back(Launch{lanes, k, (uint32_t)i, 0, 0});
         launches.back().count++;
         const uint32_t l1 = b->ref_len[b->pair_ref[p]], l2 = b->seq_len[b->pair_seq[p]];
+        launches.back().max_len1 = std::max(launches.back().max_len1, l1);
         bt_off[p] = bt_words;
         bt_words += (uint64_t)(l1 + lanes - 1) * lanes * swhip::bt_words(k);
         scr_off[p] = scr_slots;
@@ -275,6 +276,7 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     for (const Launch &l : launches) {
         a.order = reinterpret_cast<const uint32_t *>(base + o_order) + l.first;
         a.n_pairs = l.count;
+        a.lds_stride = (l.max_len1 + 15u) & ~15u;
         HIP_TRY(swhip::launch_sw(l.k, l.lanes, a, st));
     }
     HIP_TRY(hipEventRecord(c->ev1, st));

@@ -39,10 +39,11 @@ struct SwArgs
     const uint32_t *pair_ref, *pair_seq;
     const uint32_t *order;      // pairs of this launch, in processing order
     uint32_t n_pairs;
+    uint32_t lds_stride;        // bytes of LDS per alignment: the longest seq1 of the launch, rounded up
     int32_t w_match, w_mismatch, w_open, w_extend;
     uint32_t *bt;               // backtrack words; pair p starts at bt_off[p]; [step][lane][word]
     const uint64_t *bt_off;
-    int32_t *scratch;           // per pair: last-column H (len1 * cols-per-lane), last-row H (len2), element buffer
+    int32_t *scratch;           // per pair: last-column H (len1), last-row H (len2), element buffer
     const uint64_t *scratch_off;
     Alignment *out;             // [pair]
     uint32_t *cigars;           // compact element array, allocated with atomicAdd on *cigar_cursor
@@ -54,7 +55,8 @@ inline __host__ __device__ uint32_t bt_words(int cols_per_lane) { return (uint32
 // int32 slots of scratch a pair needs with the given geometry
 inline __host__ __device__ uint64_t scratch_slots(uint32_t len1, uint32_t len2, int cols_per_lane)
 {
-    return (uint64_t)len1 * (uint64_t)cols_per_lane + len2 + (uint64_t)len1 + len2 + 8u;
+    (void)cols_per_lane;
+    return (uint64_t)len1 + len2 + (uint64_t)len1 + len2 + 8u;  // last column, last row, element buffer
 }
 
 hipError_t launch_sw(int cols_per_lane, int lanes_per_pair, const SwArgs &a, hipStream_t s);

@@ -46,6 +46,7 @@ __device__ __forceinline__ int32_t group_max(int32_t v)
 template <int K, int G>
 __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
 {
+    extern __shared__ uint8_t lds_seq1[];  // [alignments per block][lds_stride]: seq1 of each alignment
     constexpr uint32_t W = (K + 7) / 8;  // backtrack words per lane per step
     const uint32_t lane = threadIdx.x & (G - 1);
     const uint32_t gidx = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
@@ -56,8 +57,8 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     const uint8_t *__restrict__ s1 = a.ref_bases + a.ref_off[r];
     const uint8_t *__restrict__ s2 = a.seq_bases + a.seq_off[s];
     uint32_t *__restrict__ bt = a.bt + a.bt_off[pair];
-    int32_t *__restrict__ lastcol = a.scratch + a.scratch_off[pair];  // [i-1][k] of the lane that owns column ncol
-    int32_t *__restrict__ lastrow = lastcol + (size_t)nrow * K;        // [j-1]
+    int32_t *__restrict__ lastcol = a.scratch + a.scratch_off[pair];  // [i-1]: H[i][ncol]
+    int32_t *__restrict__ lastrow = lastcol + nrow;                    // [j-1]: H[nrow][j]
     uint32_t *__restrict__ elems = reinterpret_cast<uint32_t *>(lastrow + ncol);
     const int32_t w_match = a.w_match, w_mismatch = a.w_mismatch, w_open = a.w_open, w_extend = a.w_extend;
 
@@ -72,6 +73,11 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
         F[k] = kLowInit;   // F[0][j] = LOW_INIT   (sw_avx.c:117-119, :198)
     }
     const uint32_t lc = (uint32_t)(ncol - 1) / K, kc = (uint32_t)(ncol - 1) % K;  // where column ncol lives
+    // seq1 is read one base per step per lane: park it in LDS (a byte load from LDS instead of a vector memory instruction)
+    uint8_t *my1 = lds_seq1 + (threadIdx.x / G) * a.lds_stride;
+    if (valid)
+        for (int32_t x = (int32_t)lane; x < nrow; x += G) my1[x] = s1[x];
+    __syncthreads();
 
     // what this lane hands to its right neighbour: H and E of its last column in the row it has just finished; before its
     // first row that is column 0 of ... no: row 0 of that column, H = 0 and E = LOW_INIT, which is also what lane 0 keeps
@@ -87,20 +93,20 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     }
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
 
-    uint32_t next1 = (lane == 0 && nrow > 0) ? (uint32_t)s1[0] : 0u;  // seq1 base of the row this lane does next
+    uint32_t next1 = (valid && lane == 0) ? (uint32_t)my1[0] : 0u;  // seq1 base of the row this lane does next
     for (int32_t t = 1; t <= Tmax; ++t) {
         const int32_t i = t - (int32_t)lane;  // this lane's row
-        const bool active = i >= 1 && i <= nrow;
+        const bool active = valid && i >= 1 && i <= nrow;
         const int32_t diag0 = inH;            // H[i-1][jL]: what came in one step ago
         inH = shr1<G>(inH, outH);
         inE = shr1<G>(inE, outE);
         const uint32_t base1 = next1;
         {
             const int32_t ni = i + 1;  // prefetch the base of the next row while this one is computed
-            next1 = (ni >= 1 && ni <= nrow) ? (uint32_t)s1[ni - 1] : 0u;
+            next1 = (valid && ni >= 1 && ni <= nrow) ? (uint32_t)my1[ni - 1] : 0u;
         }
         if (active) {
-            int32_t hl = inH, e = inE, hd = diag0;
+            int32_t hl = inH, e = inE, hd = diag0, h_ncol = 0;
             uint32_t words[W];
 #pragma unroll
             for (uint32_t w = 0; w < W; ++w) words[w] = 0;
@@ -122,6 +128,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 flag |= del ? (uint32_t)kBtDelete : (ins ? (uint32_t)kBtInsert : 0u);
                 words[k / 8] |= flag << (4 * (k % 8));
                 hd = Hp[k];  // the diagonal of the next column
+                h_ncol = (uint32_t)k == kc ? h11 : h_ncol;
                 Hp[k] = h11;
                 F[k] = f11;
                 hl = h11;
@@ -132,10 +139,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
             uint32_t *dst = bt + ((size_t)(t - 1) * G + lane) * W;
 #pragma unroll
             for (uint32_t w = 0; w < W; ++w) dst[w] = words[w];
-            if (lane == lc) {  // column ncol, every row
-#pragma unroll
-                for (int k = 0; k < K; ++k) lastcol[(size_t)(i - 1) * K + k] = Hp[k];
-            }
+            if (lane == lc) lastcol[i - 1] = h_ncol;  // column ncol, every row
             if (i == nrow) {  // row nrow, every column
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     int32_t best = INT32_MIN;
     if (valid) {
         for (int32_t j = (int32_t)lane; j < ncol; j += G) best = max(best, lastrow[j]);
-        for (int32_t i = (int32_t)lane; i < nrow; i += G) best = max(best, lastcol[(size_t)i * K + kc]);
+        for (int32_t i = (int32_t)lane; i < nrow; i += G) best = max(best, lastcol[i]);
     }
     best = group_max<G>(best);
     // Phase 2: the cells that attain it, in the reference's order (anti-diagonal ascending; on one anti-diagonal the
@@ -167,7 +171,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
             bool eq_a = false, eq_b = false;
             if (ad <= nrow + ncol) {
                 if (ad >= nrow + 1) eq_a = lastrow[ad - nrow - 1] == best;                          // cell (nrow, ad - nrow)
-                if (ad >= ncol + 1) eq_b = lastcol[(size_t)(ad - ncol - 1) * K + kc] == best;      // cell (ad - ncol, ncol)
+                if (ad >= ncol + 1) eq_b = lastcol[ad - ncol - 1] == best;  // cell (ad - ncol, ncol)
             }
             uint64_t ma = (__ballot(eq_a) >> gshift), mb = (__ballot(eq_b) >> gshift);
             if (G < 64) {
@@ -276,7 +280,7 @@ static hipError_t launch_one(const SwArgs &a, hipStream_t s)
 {
     const uint32_t per_block = kBlockThreads / G;
     const uint32_t blocks = (a.n_pairs + per_block - 1) / per_block;
-    hipLaunchKernelGGL((sw_kernel<K, G>), dim3(blocks), dim3(kBlockThreads), 0, s, a);
+    hipLaunchKernelGGL((sw_kernel<K, G>), dim3(blocks), dim3(kBlockThreads), (size_t)per_block * a.lds_stride, s, a);
     return hipGetLastError();
 }
 

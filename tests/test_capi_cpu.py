@@ -46,3 +46,25 @@ def test_no_cpu_fallback_without_device():
         pytest.skip("a GPU is visible")
     with pytest.raises(capi.PhmmError, match="no HIP device|no CPU fallback|does not exist"):
         capi.Engine(0)
+
+
+# ---- Smith-Waterman library (include/smithwaterman_hip.h) ----
+def test_sw_library_exports_every_declared_symbol_and_refuses_without_device():
+    from rovaca_amd import swapi
+
+    text = open(os.path.join(ROOT, "include", "smithwaterman_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(swhip_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["swhip_abi_version", "swhip_align", "swhip_create", "swhip_destroy", "swhip_last_error"]
+    L = swapi.lib()
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/smithwaterman_hip.h but not exported"
+    assert L.swhip_abi_version() == 1
+    # swhip_batch: 2 x u32 + u64 + 8 pointers; swhip_alignment: 20 bytes; swhip_stats: u64 + 2 x f64 + u32 (+ pad)
+    assert ctypes.sizeof(swapi.SwBatch) == 16 + 8 * 8
+    assert swapi.ALIGNMENT_DTYPE.itemsize == 20
+    assert ctypes.sizeof(swapi.SwStats) == 32
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback|swhip_create failed"):
+            swapi.Aligner(0)
