@@ -1,0 +1,152 @@
+// sw_gpu_engine.cpp -- see sw_gpu_engine.h.  Host glue only: the alignment itself is include/smithwaterman_hip.h.
+#include "sw_gpu_engine.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/smithwaterman_hip.h"
+
+namespace
+{
+
+struct ThreadContext
+{
+    swhip_context *ctx = nullptr;
+    ~ThreadContext()
+    {
+        if (ctx) swhip_destroy(ctx);
+    }
+    swhip_context *get()
+    {
+        if (!ctx && swhip_create(0, nullptr, &ctx) != SWHIP_OK) {
+            fprintf(stderr, "[rovaca_amd] smith-waterman: cannot create a device context: %s\n", swhip_last_error());
+            exit(EXIT_FAILURE);  // as the reference does on an unusable engine (pairhmm_engine.cpp:32-35)
+        }
+        return ctx;
+    }
+};
+thread_local ThreadContext t_ctx;
+
+}  // namespace
+
+namespace rovaca
+{
+
+bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, std::vector<SwAlignment> &out)
+{
+    out.assign(n, SwAlignment{});
+    if (n == 0) return true;
+    std::vector<uint8_t> refs, seqs;
+    std::vector<uint32_t> roff(n), rlen(n), soff(n), slen(n), idx(n);
+    size_t cap = 0;
+    for (size_t k = 0; k < n; ++k) {
+        roff[k] = (uint32_t)refs.size();
+        rlen[k] = (uint32_t)jobs[k].ref_len;
+        refs.insert(refs.end(), jobs[k].ref, jobs[k].ref + jobs[k].ref_len);
+        soff[k] = (uint32_t)seqs.size();
+        slen[k] = (uint32_t)jobs[k].seq_len;
+        seqs.insert(seqs.end(), jobs[k].seq, jobs[k].seq + jobs[k].seq_len);
+        idx[k] = (uint32_t)k;
+        cap += (size_t)jobs[k].ref_len + (size_t)jobs[k].seq_len + 2;
+    }
+    swhip_batch b{};
+    b.n_refs = b.n_seqs = (uint32_t)n;
+    b.n_pairs = n;
+    b.ref_bases = refs.data();
+    b.ref_off = roff.data();
+    b.ref_len = rlen.data();
+    b.seq_bases = seqs.data();
+    b.seq_off = soff.data();
+    b.seq_len = slen.data();
+    b.pair_ref = idx.data();
+    b.pair_seq = idx.data();
+    const swhip_params prm{para.match, para.mismatch, para.gap_open, para.gap_extend};
+    std::vector<swhip_alignment> res(n);
+    std::vector<uint32_t> cigars(cap);
+    uint64_t used = 0;
+    if (swhip_align(t_ctx.get(), &prm, &b, res.data(), cigars.data(), cap, &used, nullptr) != SWHIP_OK) {
+        fprintf(stderr, "[rovaca_amd] smith-waterman: %s\n", swhip_last_error());
+        return false;
+    }
+    for (size_t k = 0; k < n; ++k) {
+        out[k].score = res[k].score;
+        out[k].max_i = res[k].max_i;
+        out[k].max_j = res[k].max_j;
+        out[k].alignment_offset = res[k].alignment_offset;
+        out[k].too_long = res[k].too_long != 0;
+        out[k].cigar.assign(cigars.begin() + res[k].cigar_off, cigars.begin() + res[k].cigar_off + res[k].cigar_count);
+    }
+    return true;
+}
+
+}  // namespace rovaca
+
+extern "C" {
+
+void sw_hip_run(p_lib_sw_avx p)
+{
+    const int len = p->len1 > p->len2 ? p->len1 : p->len2;
+    if (len >= p->max_seq_len || len >= SWHIP_MAX_SEQ_LEN) {  // sw_avx.c:490-495
+        p->alignment_offset = 1;
+        return;
+    }
+    const rovaca::SwJob job{p->seq1, p->len1, p->seq2, p->len2};
+    std::vector<rovaca::SwAlignment> out;
+    if (!rovaca::sw_hip_align_batch(&job, 1, p->para, out)) exit(EXIT_FAILURE);
+    p->score = out[0].score;
+    p->max_i = out[0].max_i;
+    p->max_j = out[0].max_j;
+    p->alignment_offset = out[0].alignment_offset;
+    uint32_t count = (uint32_t)out[0].cigar.size();
+    if (count > p->cigar_max_len) count = p->cigar_max_len;
+    memcpy(p->cigar, out[0].cigar.data(), count * sizeof(uint32_t));
+    p->cigar_count = count;
+}
+
+int sw_hip_install(p_lib_sw_avx p)
+{
+    if (!p) return 0;
+    swhip_context *probe = nullptr;
+    if (swhip_create(0, nullptr, &probe) != SWHIP_OK) return 0;  // no device: the AVX selection stays
+    swhip_destroy(probe);
+    p->avx_function = sw_hip_run;
+    return 1;
+}
+
+// Test shim (plain C types for ctypes): builds a handle the way sw_avx_init lays it out (sw_avx.c:401-437, buffers only as
+// far as sw_hip_run needs them), installs the GPU candidate, runs one alignment through the function pointer.
+int rovaca_amd_sw_run_through_handle(const uint8_t *seq1, int32_t len1, const uint8_t *seq2, int32_t len2, int is_assemble,
+                                     int32_t *score, int32_t *max_i, int32_t *max_j, int32_t *alignment_offset, uint32_t *cigar,
+                                     uint32_t cigar_cap, uint32_t *cigar_count)
+{
+    const uint32_t max_seq = SWHIP_MAX_SEQ_LEN;
+    const size_t bytes = sizeof(lib_sw_avx) + 2 * (size_t)max_seq + max_seq * sizeof(uint32_t);
+    p_lib_sw_avx p = (p_lib_sw_avx)calloc(1, bytes);
+    if (!p) return -2;
+    p->max_seq_len = (int32_t)max_seq;
+    p->seq1 = p->data;
+    p->seq2 = p->data + max_seq;
+    p->cigar = (uint32_t *)(p->data + 2 * (size_t)max_seq);
+    p->cigar_max_len = max_seq;
+    p->para = is_assemble ? sw_parameters{200, -150, -260, -11} : sw_parameters{10, -15, -30, -5};  // sw_avx.c:13-14
+    if (!sw_hip_install(p)) {
+        free(p);
+        return -1;
+    }
+    if ((uint32_t)len1 < max_seq) memcpy(p->seq1, seq1, (size_t)len1);
+    if ((uint32_t)len2 < max_seq) memcpy(p->seq2, seq2, (size_t)len2);
+    p->len1 = (int16_t)len1;
+    p->len2 = (int16_t)len2;
+    p->avx_function(p);
+    *score = p->score;
+    *max_i = p->max_i;
+    *max_j = p->max_j;
+    *alignment_offset = p->alignment_offset;
+    *cigar_count = p->cigar_count;
+    for (uint32_t k = 0; k < p->cigar_count && k < cigar_cap; ++k) cigar[k] = p->cigar[k];
+    free(p);
+    return 0;
+}
+
+}  // extern "C"

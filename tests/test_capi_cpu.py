@@ -68,3 +68,9 @@ def test_sw_library_exports_every_declared_symbol_and_refuses_without_device():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback|swhip_create failed"):
             swapi.Aligner(0)
+
+
+def test_sw_host_adapter_exports_the_seam_candidates():
+    L = ctypes.CDLL(os.path.join(ROOT, "rovaca_amd", "lib", "librovaca_sw_host.so"))
+    for n in ("sw_hip_run", "sw_hip_install", "rovaca_amd_sw_run_through_handle"):
+        assert hasattr(L, n)

@@ -118,3 +118,37 @@ def test_too_long_and_invalid(aligner):
         aligner.align([b"ACGT"], [b"AC"], [(0, 1)])
     out, cig, _ = aligner.align([], [], [])
     assert len(out) == 0 and len(cig) == 0
+
+
+def test_drop_in_candidate_through_the_reference_handle():
+    # sw_hip_run installed into lib_sw_avx.avx_function and called the way the reference's call sites do
+    # (alignment_utils.cpp:572-579): same fields out as sw_avx512_run, for both parameter sets, including the length guard
+    import ctypes as C
+    L = C.CDLL(os.path.join(os.path.dirname(swapi.__file__), "lib", "librovaca_sw_host.so"))
+    i32 = C.POINTER(C.c_int32)
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    L.rovaca_amd_sw_run_through_handle.argtypes = [u8p, C.c_int32, u8p, C.c_int32, C.c_int, i32, i32, i32, i32, u32p, C.c_uint32,
+                                                   C.POINTER(C.c_uint32)]
+    L.rovaca_amd_sw_run_through_handle.restype = C.c_int
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for t in range(12):
+        n1 = int(rng.integers(20, 600)) if t < 10 else 2048
+        ref = acgt[rng.integers(0, 4, n1)]
+        n2 = int(rng.integers(5, min(n1, 300)))
+        a = int(rng.integers(0, n1 - n2 + 1))
+        seq = np.ascontiguousarray(ref[a:a + n2].copy())
+        seq[rng.random(n2) < 0.05] = ord("G")
+        for asm in (0, 1):
+            sc, mi, mj, off, cnt = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint32()
+            cig = np.zeros(n1 + n2 + 8, np.uint32)
+            rc = L.rovaca_amd_sw_run_through_handle(np.ascontiguousarray(ref), n1, seq, n2, asm, C.byref(sc), C.byref(mi),
+                                                    C.byref(mj), C.byref(off), cig, len(cig), C.byref(cnt))
+            assert rc == 0
+            o = oracle.sw_align(ref, seq, oracle.SW_PARAMS_ASSEMBLE if asm else oracle.SW_PARAMS_GENOTYPE)
+            if o["too_long"]:
+                assert off.value == 1 and cnt.value == 0
+                continue
+            assert (sc.value, mi.value, mj.value, off.value) == (o["score"], o["max_i"], o["max_j"], o["alignment_offset"])
+            assert np.array_equal(cig[:cnt.value], o["cigar"])
