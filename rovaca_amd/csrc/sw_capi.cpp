@@ -150,6 +150,9 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     if (n > 0xFFFFFFF0ull) return fail(SWHIP_E_INVALID, "swhip_align: more than 2^32 alignments in one batch");
     if (!b->ref_bases || !b->ref_off || !b->ref_len || !b->seq_bases || !b->seq_off || !b->seq_len || !b->pair_ref || !b->pair_seq)
         return fail(SWHIP_E_INVALID, "swhip_align: null table pointer");
+    // the kernel keeps scores in 31 bits around a bias (sw_device.h): penalties of the reference are below 300
+    for (int32_t w : {params->match, params->mismatch, params->gap_open, params->gap_extend})
+        if (w > 65536 || w < -65536) return fail(SWHIP_E_INVALID, "swhip_align: scoring parameter %d outside [-65536, 65536]", w);
     HIP_TRY(hipSetDevice(c->device));
 
     // ---- validate, find extents ----
@@ -211,7 +214,7 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
         const uint32_t l1 = b->ref_len[b->pair_ref[p]], l2 = b->seq_len[b->pair_seq[p]];
         launches.back().max_len1 = std::max(launches.back().max_len1, l1);
         bt_off[p] = bt_words;
-        bt_words += (uint64_t)(l1 + lanes - 1) * lanes * swhip::bt_words(k);
+        bt_words += swhip::bt_words(l1, lanes, k);
         scr_off[p] = scr_slots;
         scr_slots += swhip::scratch_slots(l1, l2, k);
     }

@@ -11,6 +11,11 @@ namespace swhip
 constexpr int kBlockThreads = 256;
 constexpr int kMaxSeqLen = 2048;                    // sw_avx.c:17: sequences of this length or more are not aligned
 constexpr int32_t kLowInit = INT32_MIN / 2;         // sw_avx.c:19
+// The kernel keeps scores biased by 2^30 so that unsigned compares order them.  LOW_INIT itself would be 0 there and
+// LOW_INIT + gap_extend would wrap, so the kernel's "minus infinity" is 2^20 above it: still a billion below any real score
+// (|score| < 2^20 for sequences under 2048 bases and penalties under 512), which is all the recurrence needs of it.
+constexpr uint32_t kBias = 1u << 30;
+constexpr uint32_t kLowBiased = 1u << 20;
 constexpr int kMaxColsPerLaneNarrow = 16;           // 16 lanes per alignment: seq2 up to 256 bases
 constexpr int kMaxColsPerLaneWide = 32;             // 64 lanes per alignment: seq2 up to 2048 bases
 
@@ -41,7 +46,7 @@ struct SwArgs
     uint32_t n_pairs;
     uint32_t lds_stride;        // bytes of LDS per alignment: the longest seq1 of the launch, rounded up
     int32_t w_match, w_mismatch, w_open, w_extend;
-    uint32_t *bt;               // backtrack words; pair p starts at bt_off[p]; [step][lane][word]
+    uint32_t *bt;               // backtrack flags; pair p starts at bt_off[p] (see bt_words)
     const uint64_t *bt_off;
     int32_t *scratch;           // per pair: last-column H (len1), last-row H (len2), element buffer
     const uint64_t *scratch_off;
@@ -50,8 +55,18 @@ struct SwArgs
     uint32_t *cigar_cursor;
 };
 
-// words of backtrack flags a lane writes per step
-inline __host__ __device__ uint32_t bt_words(int cols_per_lane) { return (uint32_t)(cols_per_lane + 7) / 8u; }
+// backtrack flags: 4 bits per cell; a lane's K cells of a step are K / 8 full dwords plus a tail of 1, 2 or 4 bytes
+inline __host__ __device__ constexpr uint32_t bt_tail_bytes(int cols_per_lane)
+{
+    return cols_per_lane % 8 == 0 ? 0u : cols_per_lane % 8 <= 2 ? 1u : cols_per_lane % 8 <= 4 ? 2u : 4u;
+}
+// dwords of backtrack storage of one alignment: [steps][lanes][K / 8] dwords, then [steps][lanes] tails, rounded up to 128 B
+inline __host__ __device__ uint64_t bt_words(uint32_t len1, int lanes, int cols_per_lane)
+{
+    const uint64_t slots = (uint64_t)(len1 + lanes - 1) * lanes;
+    const uint64_t words = slots * (uint64_t)(cols_per_lane / 8) + (slots * bt_tail_bytes(cols_per_lane) + 3) / 4;
+    return (words + 31) & ~uint64_t(31);
+}
 // int32 slots of scratch a pair needs with the given geometry
 inline __host__ __device__ uint64_t scratch_slots(uint32_t len1, uint32_t len2, int cols_per_lane)
 {

@@ -14,7 +14,7 @@
 // alignments per wave, DPP row_shr; 64: one per wave, wave_shr); lane l owns K consecutive columns of seq2 in VGPRs (H and F of
 // the row above, the bases), and at step t computes row t - l of its columns.  E runs left to right inside the lane and
 // crosses to the next lane together with H through two DPP moves per step; the lane keeps last step's incoming H as the
-// diagonal of its first column.  Backtrack flags are 4 bits per cell, packed 8 per dword, stored [step][lane][word].
+// diagonal of its first column.  Backtrack flags are 4 sign bits per cell, appended with v_alignbit, 8 cells per dword.
 // The end-cell search is a parallel max followed by an in-order pass over the few cells that attain it; the traceback is
 // one lane walking the flags (latency-bound, overlapped with other waves' sweeps).
 #include <hip/hip_runtime.h>
@@ -47,7 +47,11 @@ template <int K, int G>
 __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
 {
     extern __shared__ uint8_t lds_seq1[];  // [alignments per block][lds_stride]: seq1 of each alignment
-    constexpr uint32_t W = (K + 7) / 8;  // backtrack words per lane per step
+    constexpr uint32_t W = (K + 7) / 8;  // backtrack words a lane produces per step
+    // they are stored as W32 full dwords plus a tail of 1, 2 or 4 bytes for the last K % 8 cells, in two arrays
+    // ([step][lane][W32] dwords, then [step][lane] tails): the kernel is bound by these writes, so 10 columns per lane cost
+    // 5 bytes per step instead of 8
+    constexpr uint32_t W32 = K / 8, TAILB = bt_tail_bytes(K);
     const uint32_t lane = threadIdx.x & (G - 1);
     const uint32_t gidx = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
     const bool valid = gidx < a.n_pairs;
@@ -57,20 +61,22 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     const uint8_t *__restrict__ s1 = a.ref_bases + a.ref_off[r];
     const uint8_t *__restrict__ s2 = a.seq_bases + a.seq_off[s];
     uint32_t *__restrict__ bt = a.bt + a.bt_off[pair];
+    uint8_t *__restrict__ bt_tail = reinterpret_cast<uint8_t *>(bt + (size_t)(nrow + G - 1) * G * (K / 8));
     int32_t *__restrict__ lastcol = a.scratch + a.scratch_off[pair];  // [i-1]: H[i][ncol]
     int32_t *__restrict__ lastrow = lastcol + nrow;                    // [j-1]: H[nrow][j]
     uint32_t *__restrict__ elems = reinterpret_cast<uint32_t *>(lastrow + ncol);
-    const int32_t w_match = a.w_match, w_mismatch = a.w_mismatch, w_open = a.w_open, w_extend = a.w_extend;
+    const uint32_t w_match = (uint32_t)a.w_match, w_mismatch = (uint32_t)a.w_mismatch, w_open = (uint32_t)a.w_open,
+                   w_extend = (uint32_t)a.w_extend;
 
     // ---- per-column state ----
-    int32_t Hp[K], F[K];   // H[i-1][j], F[i-1][j] of this lane's columns
+    uint32_t Hp[K], F[K];  // H[i-1][j], F[i-1][j] of this lane's columns, biased by kBias
     uint32_t base2[K];     // seq2[j]; columns past the end never match (their cells feed nothing)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int32_t j = (int32_t)lane * K + k + 1;
         base2[k] = j <= ncol ? (uint32_t)s2[j - 1] : 0x100u;
-        Hp[k] = 0;         // H[0][j] = 0          (sw_avx.c:196)
-        F[k] = kLowInit;   // F[0][j] = LOW_INIT   (sw_avx.c:117-119, :198)
+        Hp[k] = kBias;     // H[0][j] = 0          (sw_avx.c:196)
+        F[k] = kLowBiased; // F[0][j] = LOW_INIT   (sw_avx.c:117-119, :198)
     }
     const uint32_t lc = (uint32_t)(ncol - 1) / K, kc = (uint32_t)(ncol - 1) % K;  // where column ncol lives
     // seq1 is read one base per step per lane: park it in LDS (a byte load from LDS instead of a vector memory instruction)
@@ -82,8 +88,8 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     // what this lane hands to its right neighbour: H and E of its last column in the row it has just finished; before its
     // first row that is column 0 of ... no: row 0 of that column, H = 0 and E = LOW_INIT, which is also what lane 0 keeps
     // receiving from the left edge (H[i][0] = 0, E[i][0] = LOW_INIT; sw_avx.c:120-122, :197, :199)
-    int32_t outH = 0, outE = kLowInit;
-    int32_t inH = 0, inE = kLowInit;  // received this step: H[i][jL], E[i][jL] with jL the neighbour's last column
+    uint32_t outH = kBias, outE = kLowBiased;
+    uint32_t inH = kBias, inE = kLowBiased;  // received this step: H[i][jL], E[i][jL] with jL the neighbour's last column
 
     const int32_t Tg = valid ? nrow + (G - 1) : 0;
     int32_t Tmax = Tg;
@@ -97,36 +103,60 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     for (int32_t t = 1; t <= Tmax; ++t) {
         const int32_t i = t - (int32_t)lane;  // this lane's row
         const bool active = valid && i >= 1 && i <= nrow;
-        const int32_t diag0 = inH;            // H[i-1][jL]: what came in one step ago
-        inH = shr1<G>(inH, outH);
-        inE = shr1<G>(inE, outE);
+        const uint32_t diag0 = inH;           // H[i-1][jL]: what came in one step ago
+        inH = (uint32_t)shr1<G>((int32_t)inH, (int32_t)outH);
+        inE = (uint32_t)shr1<G>((int32_t)inE, (int32_t)outE);
         const uint32_t base1 = next1;
         {
             const int32_t ni = i + 1;  // prefetch the base of the next row while this one is computed
             next1 = (valid && ni >= 1 && ni <= nrow) ? (uint32_t)my1[ni - 1] : 0u;
         }
         if (active) {
-            int32_t hl = inH, e = inE, hd = diag0, h_ncol = 0;
+            uint32_t hl = inH, e = inE, hd = diag0, h_ncol = 0;
             uint32_t words[W];
 #pragma unroll
             for (uint32_t w = 0; w < W; ++w) words[w] = 0;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const int32_t ext_h = e + w_extend, open_h = hl + w_open;
-                const bool open_gt_ext_h = open_h > ext_h;
-                const int32_t e11 = open_gt_ext_h ? open_h : ext_h;
-                const int32_t ext_v = F[k] + w_extend, open_v = Hp[k] + w_open;
-                const bool open_gt_ext_v = open_v > ext_v;
-                const int32_t f11 = open_gt_ext_v ? open_v : ext_v;
-                const int32_t m11 = hd + (base1 == base2[k] ? w_match : w_mismatch);
-                int32_t h11 = m11;
-                uint32_t flag = (open_gt_ext_h ? 0u : (uint32_t)kBtInsertExt) | (open_gt_ext_v ? 0u : (uint32_t)kBtDeleteExt);
-                const bool ins = e11 > h11;
-                h11 = ins ? e11 : h11;
-                const bool del = f11 > h11;
-                h11 = del ? f11 : h11;
-                flag |= del ? (uint32_t)kBtDelete : (ins ? (uint32_t)kBtInsert : 0u);
-                words[k / 8] |= flag << (4 * (k % 8));
+                // One cell = 19 full-rate VALU instructions, written out by hand.  On gfx950 v_max_i32, v_alignbit_b32 and
+                // every compare/select that goes through an SGPR pair issue at HALF the rate of v_add_u32 / VOPC-to-VCC /
+                // v_cndmask-from-VCC / v_addc_co (tools/ubench_valu.hip), and hipcc picks exactly those.  So each maximum is
+                // a compare into VCC, a select out of VCC, and v_addc_co_u32 acc, vcc, acc, acc, vcc appends the same bit to
+                // the flag word.  Scores live biased by 2^30 (unsigned compares are then signed compares).  Two wait states
+                // are needed between a VALU write of VCC and a VALU read of it; independent work fills them where there is
+                // some, s_nop where there is none (inline assembly is not visible to the hazard recogniser).
+                uint32_t e11, f11, h11, acc = words[k / 8];
+                uint32_t t_exth, t_openh, t_sc, t_m11, t_extv, t_openv, t_h1;
+                asm volatile(
+                    "v_cmp_eq_u32 vcc, %[b1], %[b2]\n\t"
+                    "v_add_u32 %[exth], %[e], %[wext]\n\t"
+                    "v_add_u32 %[openh], %[hl], %[wopen]\n\t"
+                    "v_cndmask_b32 %[sc], %[wmm], %[wm], vcc\n\t"
+                    "v_cmp_lt_u32 vcc, %[exth], %[openh]\n\t"      // E: the gap opens here (extension wins ties)
+                    "v_add_u32 %[m11], %[hd], %[sc]\n\t"
+                    "v_add_u32 %[extv], %[fk], %[wext]\n\t"
+                    "v_cndmask_b32 %[e11], %[exth], %[openh], vcc\n\t"
+                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                    "v_add_u32 %[openv], %[hp], %[wopen]\n\t"
+                    "v_cmp_lt_u32 vcc, %[extv], %[openv]\n\t"      // F: the gap opens here
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32 %[f11], %[extv], %[openv], vcc\n\t"
+                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                    "v_cmp_lt_u32 vcc, %[m11], %[e11]\n\t"          // E beats the diagonal: insertion
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32 %[h1], %[m11], %[e11], vcc\n\t"
+                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                    "v_cmp_lt_u32 vcc, %[h1], %[f11]\n\t"           // F beats both: deletion
+                    "s_nop 1\n\t"
+                    "v_cndmask_b32 %[h11], %[h1], %[f11], vcc\n\t"
+                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
+                    : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "=&v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth),
+                      [openh] "=&v"(t_openh), [sc] "=&v"(t_sc), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv),
+                      [h1] "=&v"(t_h1)
+                    : [b1] "v"(base1), [b2] "v"(base2[k]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [fk] "v"(F[k]), [hp] "v"(Hp[k]),
+                      [wext] "v"(w_extend), [wopen] "v"(w_open), [wm] "v"(w_match), [wmm] "v"(w_mismatch)
+                    : "vcc");
+                words[k / 8] = acc;
                 hd = Hp[k];  // the diagonal of the next column
                 h_ncol = (uint32_t)k == kc ? h11 : h_ncol;
                 Hp[k] = h11;
@@ -136,15 +166,21 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
             }
             outH = hl;
             outE = e;
-            uint32_t *dst = bt + ((size_t)(t - 1) * G + lane) * W;
+            {
+                const size_t slot = (size_t)(t - 1) * G + lane;
+                uint32_t *dst = bt + slot * W32;
 #pragma unroll
-            for (uint32_t w = 0; w < W; ++w) dst[w] = words[w];
-            if (lane == lc) lastcol[i - 1] = h_ncol;  // column ncol, every row
+                for (uint32_t w = 0; w < W32; ++w) dst[w] = words[w];
+                if constexpr (TAILB == 1) bt_tail[slot] = (uint8_t)words[W - 1];
+                if constexpr (TAILB == 2) reinterpret_cast<uint16_t *>(bt_tail)[slot] = (uint16_t)words[W - 1];
+                if constexpr (TAILB == 4) reinterpret_cast<uint32_t *>(bt_tail)[slot] = words[W - 1];
+            }
+            if (lane == lc) lastcol[i - 1] = (int32_t)(h_ncol - kBias);  // column ncol, every row
             if (i == nrow) {  // row nrow, every column
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int32_t j = (int32_t)lane * K + k + 1;
-                    if (j <= ncol) lastrow[j - 1] = Hp[k];
+                    if (j <= ncol) lastrow[j - 1] = (int32_t)(Hp[k] - kBias);
                 }
             }
         }
@@ -223,7 +259,22 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
         while (i > 0 && j > 0) {
             const uint32_t l = (uint32_t)(j - 1) / K, k = (uint32_t)(j - 1) % K;
             const uint32_t t = (uint32_t)i + l;
-            const uint32_t btr = (bt[((size_t)(t - 1) * G + l) * W + k / 8] >> (4 * (k % 8))) & 15u;
+            const size_t slot = (size_t)(t - 1) * G + l;
+            uint32_t word;
+            if (k / 8 < W32)
+                word = bt[slot * W32 + k / 8];
+            else if (TAILB == 1)
+                word = bt_tail[slot];
+            else if (TAILB == 2)
+                word = reinterpret_cast<const uint16_t *>(bt_tail)[slot];
+            else
+                word = reinterpret_cast<const uint32_t *>(bt_tail)[slot];
+            constexpr uint32_t last_cells = K % 8 == 0 ? 8u : (uint32_t)(K % 8);      // cells in the last (partial) word
+            const uint32_t in_word = k / 8 + 1 == W ? last_cells : 8u;
+            const uint32_t nib = (word >> (4 * (in_word - 1 - k % 8))) & 15u;          // first cell of a word sits highest
+            // back to the reference's flags (smithwaterman_common.h:41-46)
+            const uint32_t btr = ((nib & 8u) ? 0u : (uint32_t)kBtInsertExt) | ((nib & 4u) ? 0u : (uint32_t)kBtDeleteExt) |
+                                 ((nib & 1u) ? (uint32_t)kBtDelete : (nib & 2u) ? (uint32_t)kBtInsert : 0u);
             if (state == kBtInsertExt) {
                 --j;
                 cur_len += 1;  // lengthens the insertion that is being built

@@ -14,3 +14,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   echo "pmc $grp done"
 done
 find $OUT -name "*.csv" | head -30
+# Smith-Waterman aligner: kernel trace of tools/bench_sw.py
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sw -o sw -- python3 tools/bench_sw.py --regions 1000 --no-cpu > $OUT/bench_sw.log 2>&1
+tail -1 $OUT/bench_sw.log | cut -c1-200
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/pmc_sw -o pmc -- python3 tools/bench_sw.py --regions 1000 --no-cpu --iters 2 > $OUT/pmc_sw.log 2>&1
+echo "pmc sw done"

@@ -27,6 +27,11 @@ __global__ void k(float* out, int iters, unsigned long long* clk)
         if (MODE == 4) { REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %0\n v_cndmask_b32 %2, %8, %9, vcc\n v_add_co_u32 %1, vcc, %1, %1\n v_cndmask_b32 %3, %8, %9, vcc\n v_add_co_u32 %0, vcc, %0, %0\n v_cndmask_b32 %4, %8, %9, vcc\n v_add_co_u32 %1, vcc, %1, %1\n v_cndmask_b32 %5, %8, %9, vcc" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");) }
         if (MODE == 5) { REP8(asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));) }
         if (MODE == 6) { REP8(asm volatile("s_nop 1\n v_mul_f32_dpp %0, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_fmac_f32_dpp %2, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mul_f32_dpp %4, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_fmac_f32_dpp %6, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mul_f32_dpp %1, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_fmac_f32_dpp %3, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mul_f32_dpp %5, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_fmac_f32_dpp %7, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (MODE == 8) { REP8(asm volatile("v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %2\n v_add_u32 %3, %3, %2\n v_add_u32 %4, %4, %2\n v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %2\n v_add_u32 %3, %3, %2\n v_add_u32 %4, %4, %2" : "+v"(m0), "+v"(m1) : "v"(m0 | 1u), "v"(a2), "v"(a3));) }
+        if (MODE == 9) { REP8(asm volatile("v_max_i32 %0, %0, %2\n v_max_i32 %1, %1, %2\n v_max_i32 %0, %0, %3\n v_max_i32 %1, %1, %3\n v_max_i32 %0, %0, %2\n v_max_i32 %1, %1, %2\n v_max_i32 %0, %0, %3\n v_max_i32 %1, %1, %3" : "+v"(m0), "+v"(m1) : "v"(a2), "v"(a3));) }
+        if (MODE == 10) { REP8(asm volatile("v_sub_u32 %2, %0, %1\n v_alignbit_b32 %3, %3, %2, 31\n v_sub_u32 %4, %1, %0\n v_alignbit_b32 %3, %3, %4, 31\n v_sub_u32 %2, %0, %1\n v_alignbit_b32 %3, %3, %2, 31\n v_sub_u32 %4, %1, %0\n v_alignbit_b32 %3, %3, %4, 31" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        if (MODE == 11) { REP8(asm volatile("v_cmp_eq_u32_e64 s[20:21], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %2, %4, %5, s[20:21]\n v_cmp_gt_i32_e64 s[22:23], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %3, %4, %5, s[22:23]\n v_cmp_eq_u32_e64 s[20:21], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %2, %4, %5, s[20:21]\n v_cmp_gt_i32_e64 s[22:23], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %3, %4, %5, s[22:23]" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "s20", "s21", "s22", "s23");) }
+        if (MODE == 12) { REP8(asm volatile("v_alignbit_b32 %0, %0, %1, 31\n v_alignbit_b32 %2, %2, %1, 31\n v_alignbit_b32 %3, %3, %1, 31\n v_alignbit_b32 %4, %4, %1, 31\n v_alignbit_b32 %0, %0, %1, 31\n v_alignbit_b32 %2, %2, %1, 31\n v_alignbit_b32 %3, %3, %1, 31\n v_alignbit_b32 %4, %4, %1, 31" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 7) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -109,6 +114,11 @@ int main()
     run<6>("v_mul/fmac_f32_dpp row_shr:1", out, clk);
     run<4>("v_add_co_u32 + v_cndmask_b32", out, clk);
     run<5>("v_fma_f64 (4 indep)", out, clk);
+    run<8>("v_add_u32 (4 indep)", out, clk);
+    run<9>("v_max_i32 (2 chains)", out, clk);
+    run<10>("v_sub_u32 + v_alignbit_b32", out, clk);
+    run<12>("v_alignbit_b32 (4 indep)", out, clk);
+    run<11>("v_cmp_e64 sgpr + s_nop 1 + v_cndmask_e64 (counted as 2)", out, clk);
     run_salu<0>("8 v_fma + 0 SALU", out, clk);
     run_salu<2>("8 v_fma + 4 SALU (interleaved)", out, clk);
     run_salu<4>("8 v_fma + 8 SALU (interleaved)", out, clk);
