@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 // the flag word.  Scores live biased by 2^30 (unsigned compares are then signed compares).  Two wait states
                 // are needed between a VALU write of VCC and a VALU read of it; independent work fills them where there is
                 // some, s_nop where there is none (inline assembly is not visible to the hazard recogniser).
-                uint32_t e11, f11, h11, acc = words[k / 8];
+                uint32_t e11, f11 = F[k], h11, acc = words[k / 8];  // f11: F[i-1][j] in, F[i][j] out
                 uint32_t t_exth, t_openh, t_sc, t_m11, t_extv, t_openv, t_h1;
                 asm volatile(
                     "v_cmp_eq_u32 vcc, %[b1], %[b2]\n\t"
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                     "v_cndmask_b32 %[sc], %[wmm], %[wm], vcc\n\t"
                     "v_cmp_lt_u32 vcc, %[exth], %[openh]\n\t"      // E: the gap opens here (extension wins ties)
                     "v_add_u32 %[m11], %[hd], %[sc]\n\t"
-                    "v_add_u32 %[extv], %[fk], %[wext]\n\t"
+                    "v_add_u32 %[extv], %[f11], %[wext]\n\t"
                     "v_cndmask_b32 %[e11], %[exth], %[openh], vcc\n\t"
                     "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
                     "v_add_u32 %[openv], %[hp], %[wopen]\n\t"
@@ -150,10 +150,10 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                     "s_nop 1\n\t"
                     "v_cndmask_b32 %[h11], %[h1], %[f11], vcc\n\t"
                     "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
-                    : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "=&v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth),
+                    : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "+v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth),
                       [openh] "=&v"(t_openh), [sc] "=&v"(t_sc), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv),
                       [h1] "=&v"(t_h1)
-                    : [b1] "v"(base1), [b2] "v"(base2[k]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [fk] "v"(F[k]), [hp] "v"(Hp[k]),
+                    : [b1] "v"(base1), [b2] "v"(base2[k]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [hp] "v"(Hp[k]),
                       [wext] "v"(w_extend), [wopen] "v"(w_open), [wm] "v"(w_match), [wmm] "v"(w_mismatch)
                     : "vcc");
                 words[k / 8] = acc;
