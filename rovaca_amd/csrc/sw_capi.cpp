@@ -196,7 +196,9 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     // ---- per-pair device offsets ----
     std::vector<uint32_t> order(m);
     std::vector<uint64_t> bt_off(n, 0), scr_off(n, 0);
-    uint64_t bt_words = 0, scr_slots = 0;
+    uint64_t bt_words = 0, bt_peak = 0, scr_slots = 0;
+    uint64_t kBtWordsPerLaunch = 1ull << 30;
+    if (const char *e = getenv("SWHIP_BT_WORDS_PER_LAUNCH")) kBtWordsPerLaunch = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // tests
     struct Launch
     {
         int lanes, k;
@@ -208,13 +210,19 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
         const uint64_t cls = keys[i] >> 48;
         const int lanes = cls >= 64 ? 64 : 16, k = (int)(cls >= 64 ? cls - 64 : cls);
         order[i] = p;
-        if (launches.empty() || launches.back().lanes != lanes || launches.back().k != k)
-            launches.push_back(Launch{lanes, k, (uint32_t)i, 0, 0});
-        launches.back().count++;
         const uint32_t l1 = b->ref_len[b->pair_ref[p]], l2 = b->seq_len[b->pair_seq[p]];
+        const uint64_t need = swhip::bt_words(l1, lanes, k);
+        // launches run one after another on the context's stream, so their backtrack storage can be the same memory: a
+        // launch ends where the next alignment would push it past kBtWordsPerLaunch (4 GiB), and the next starts at 0
+        if (launches.empty() || launches.back().lanes != lanes || launches.back().k != k || bt_words + need > kBtWordsPerLaunch) {
+            launches.push_back(Launch{lanes, k, (uint32_t)i, 0, 0});
+            bt_peak = std::max(bt_peak, bt_words);
+            bt_words = 0;
+        }
+        launches.back().count++;
         launches.back().max_len1 = std::max(launches.back().max_len1, l1);
         bt_off[p] = bt_words;
-        bt_words += swhip::bt_words(l1, lanes, k);
+        bt_words += need;
         scr_off[p] = scr_slots;
         scr_slots += swhip::scratch_slots(l1, l2, k);
     }
@@ -248,7 +256,7 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     memcpy(sp + o_scr, scr_off.data(), n * 8);
     memset(sp + o_cur, 0, 4);
     HIP_TRY(hipMemcpyAsync(c->blob.p, c->stage.p, total, hipMemcpyHostToDevice, st));
-    HIP_TRY(c->bt.ensure(bt_words * 4));
+    HIP_TRY(c->bt.ensure(std::max(bt_peak, bt_words) * 4));
     HIP_TRY(c->scratch.ensure(scr_slots * 4));
     HIP_TRY(c->out.ensure(n * sizeof(swhip::Alignment)));
     HIP_TRY(c->cigars.ensure(worst_elems * 4));

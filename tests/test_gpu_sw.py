@@ -84,6 +84,25 @@ def test_region_shaped_batch_reads_vs_best_haplotype(aligner):
     _check(aligner, refs, seqs, pairs, swapi.PARAMS_GENOTYPE)
 
 
+def test_backtrack_memory_is_reused_across_launches(aligner, monkeypatch):
+    # a batch whose backtrack flags exceed the per-launch budget is cut into launches that reuse the same memory
+    monkeypatch.setenv("SWHIP_BT_WORDS_PER_LAUNCH", "60000")
+    rng = np.random.default_rng(12)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    refs = [acgt[rng.integers(0, 4, int(rng.integers(200, 400)))] for _ in range(8)]
+    seqs, pairs = [], []
+    for k in range(60):
+        ref = refs[k % 8]
+        n = int(rng.integers(40, 150))
+        a = int(rng.integers(0, len(ref) - n))
+        s = ref[a:a + n].copy()
+        s[rng.random(n) < 0.04] = ord("A")
+        seqs.append(s)
+        pairs.append((k % 8, k))
+    out, cig, st = _check(aligner, refs, seqs, pairs, swapi.PARAMS_GENOTYPE)
+    assert st.n_launches > 3
+
+
 def test_every_geometry_and_long_sequences(aligner):
     # seq2 lengths across every columns-per-lane instantiation of both shapes (16 and 64 lanes per alignment)
     rng = np.random.default_rng(9)
