@@ -167,6 +167,9 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     }
 
     // ---- classify: (lanes per alignment, columns per lane); longest reference first inside a launch ----
+    constexpr uint64_t kWideMaxPairs = 2048;
+    int forced_lanes = 0;
+    if (const char *e = getenv("SWHIP_FORCE_LANES")) forced_lanes = atoi(e);  // tests
     std::vector<uint64_t> keys;  // class << 48 | (0xFFFF - len1) << 32 | pair
     keys.reserve(n);
     uint64_t cells = 0, worst_elems = 0;
@@ -181,7 +184,11 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
             out[p].too_long = 1;
             continue;
         }
-        const int lanes = l2 <= 16u * swhip::kMaxColsPerLaneNarrow ? 16 : 64;
+        // 16 lanes per alignment (four per wave) is the throughput shape; a batch of a region or a few would put a dozen
+        // slow waves on a chip of 1024 SIMDs, so small batches take a whole wave per alignment (half the sweep time)
+        int lanes = (l2 <= 16u * swhip::kMaxColsPerLaneNarrow && n > kWideMaxPairs) ? 16 : 64;
+        if (forced_lanes == 16 && l2 <= 16u * swhip::kMaxColsPerLaneNarrow) lanes = 16;
+        if (forced_lanes == 64) lanes = 64;
         const int k = swhip::pick_cols_per_lane(l2, lanes);
         const uint64_t cls = (uint64_t)(lanes == 16 ? 0 : 64) + (uint64_t)k;
         keys.push_back((cls << 48) | ((uint64_t)(0xFFFFu - l1) << 32) | p);

@@ -1,9 +1,14 @@
 // sw_gpu_engine.cpp -- see sw_gpu_engine.h.  Host glue only: the alignment itself is include/smithwaterman_hip.h.
 #include "sw_gpu_engine.h"
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 #include "../../include/smithwaterman_hip.h"
 
@@ -30,12 +35,15 @@ thread_local ThreadContext t_ctx;
 
 }  // namespace
 
-namespace rovaca
+namespace
 {
 
-bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, std::vector<SwAlignment> &out)
+using rovaca::SwAlignment;
+using rovaca::SwJob;
+
+// one device call for `n` jobs on the calling thread's context
+bool align_now(const SwJob *jobs, size_t n, const sw_parameters &para, SwAlignment *out)
 {
-    out.assign(n, SwAlignment{});
     if (n == 0) return true;
     std::vector<uint8_t> refs, seqs;
     std::vector<uint32_t> roff(n), rlen(n), soff(n), slen(n), idx(n);
@@ -78,6 +86,132 @@ bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, 
         out[k].cigar.assign(cigars.begin() + res[k].cigar_off, cigars.begin() + res[k].cigar_off + res[k].cigar_count);
     }
     return true;
+}
+
+// Cross-region batching, as for PairHMM (pairhmm_gpu_engine.cpp): the reference's workers realign one region at a time
+// (haplotypecaller_engine.cpp:264), 48 alignments or so -- a dozen waves.  Dispatcher threads merge every request that queued
+// up while the previous device call was in flight into one call and hand each worker its slice.
+// ROVACA_AMD_SW_BATCHING=0 bypasses it (each worker calls the device itself); ROVACA_AMD_SW_DISPATCHERS sets their number (2).
+struct Request
+{
+    const SwJob *jobs;
+    size_t n;
+    sw_parameters para;
+    SwAlignment *out;
+    bool ok = true;
+    std::atomic<bool> done{false};
+};
+
+class SwBatcher
+{
+public:
+    SwBatcher() : worker_([this] { run(); }) {}
+    bool submit_and_wait(Request &rq)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            queue_.push_back(&rq);
+        }
+        cv_.notify_one();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return rq.done.load(std::memory_order_acquire); });
+        return rq.ok;
+    }
+    std::atomic<uint64_t> requests{0}, submissions{0};
+
+private:
+    static bool same(const sw_parameters &a, const sw_parameters &b)
+    {
+        return a.match == b.match && a.mismatch == b.mismatch && a.gap_open == b.gap_open && a.gap_extend == b.gap_extend;
+    }
+    void run()
+    {
+        std::vector<Request *> taken, group;
+        std::vector<SwJob> jobs;
+        std::vector<SwAlignment> out;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !queue_.empty(); });
+                taken.assign(queue_.begin(), queue_.end());
+                queue_.clear();
+            }
+            while (!taken.empty()) {
+                group.clear();
+                const sw_parameters para = taken.front()->para;
+                for (auto it = taken.begin(); it != taken.end();) {
+                    if (same((*it)->para, para)) {
+                        group.push_back(*it);
+                        it = taken.erase(it);
+                    }
+                    else {
+                        ++it;
+                    }
+                }
+                jobs.clear();
+                for (Request *r : group) jobs.insert(jobs.end(), r->jobs, r->jobs + r->n);
+                out.assign(jobs.size(), SwAlignment{});
+                const bool ok = align_now(jobs.data(), jobs.size(), para, out.data());
+                requests += group.size();
+                submissions += 1;
+                size_t at = 0;
+                for (Request *r : group) {
+                    for (size_t k = 0; k < r->n; ++k) r->out[k] = std::move(out[at + k]);
+                    at += r->n;
+                    r->ok = ok;
+                    r->done.store(true, std::memory_order_release);
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                }
+                done_cv_.notify_all();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<Request *> queue_;
+    std::thread worker_;
+};
+
+std::vector<SwBatcher *> g_sw_batchers;  // never destroyed: their threads would call into HIP during static teardown
+std::once_flag g_sw_once;
+std::atomic<uint32_t> g_sw_next{0};
+
+void start_batchers()
+{
+    const char *on = getenv("ROVACA_AMD_SW_BATCHING");
+    if (on && atoi(on) == 0) return;
+    const char *nd = getenv("ROVACA_AMD_SW_DISPATCHERS");
+    int n = nd ? atoi(nd) : 2;
+    n = n < 1 ? 1 : n > 16 ? 16 : n;
+    for (int i = 0; i < n; ++i) g_sw_batchers.push_back(new SwBatcher());
+}
+
+}  // namespace
+
+namespace rovaca
+{
+
+bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, std::vector<SwAlignment> &out)
+{
+    out.assign(n, SwAlignment{});
+    if (n == 0) return true;
+    std::call_once(g_sw_once, start_batchers);
+    if (g_sw_batchers.empty()) return align_now(jobs, n, para, out.data());
+    Request rq{jobs, n, para, out.data()};
+    return g_sw_batchers[g_sw_next.fetch_add(1) % g_sw_batchers.size()]->submit_and_wait(rq);
+}
+
+void sw_hip_batching_stats(uint64_t *requests, uint64_t *submissions)
+{
+    uint64_t r = 0, s = 0;
+    for (SwBatcher *b : g_sw_batchers) {
+        r += b->requests;
+        s += b->submissions;
+    }
+    if (requests) *requests = r;
+    if (submissions) *submissions = s;
 }
 
 }  // namespace rovaca

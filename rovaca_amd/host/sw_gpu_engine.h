@@ -55,8 +55,12 @@ struct SwAlignment
     std::vector<uint32_t> cigar;    // BAM elements, as lib_sw_avx.cigar[0..cigar_count)
 };
 
-// All jobs in one device call (per-thread context, created on first use).  Returns false on a device error (text on stderr).
+// All jobs in one device call.  Concurrent callers (the reference's worker pool) are coalesced across regions by a couple
+// of dispatcher threads, as for PairHMM; ROVACA_AMD_SW_BATCHING=0 makes every caller use its own device context instead.
+// Returns false on a device error (text on stderr).
 bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, std::vector<SwAlignment> &out);
+// requests served and device calls made by the dispatchers
+void sw_hip_batching_stats(uint64_t *requests, uint64_t *submissions);
 
 }  // namespace rovaca
 #endif

@@ -52,7 +52,9 @@ def test_golden_vectors_bit_exact(aligner, tag):
         assert np.array_equal(swapi.cigar_of(out[k], cig), gc[coff[k]:coff[k + 1]]), k
 
 
-def test_region_shaped_batch_reads_vs_best_haplotype(aligner):
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_region_shaped_batch_reads_vs_best_haplotype(aligner, lanes, monkeypatch):
+    monkeypatch.setenv("SWHIP_FORCE_LANES", str(lanes))  # both shapes: four alignments per wave, one per wave
     # the genotyping call site: every read of a region against its best haplotype (alignment_utils.cpp:572-579)
     rng = np.random.default_rng(7)
     acgt = np.frombuffer(b"ACGT", np.uint8)
@@ -103,7 +105,9 @@ def test_backtrack_memory_is_reused_across_launches(aligner, monkeypatch):
     assert st.n_launches > 3
 
 
-def test_every_geometry_and_long_sequences(aligner):
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_every_geometry_and_long_sequences(aligner, lanes, monkeypatch):
+    monkeypatch.setenv("SWHIP_FORCE_LANES", str(lanes))
     # seq2 lengths across every columns-per-lane instantiation of both shapes (16 and 64 lanes per alignment)
     rng = np.random.default_rng(9)
     acgt = np.frombuffer(b"ACGT", np.uint8)

@@ -1,6 +1,8 @@
 // adapter_bench.cpp -- end-to-end throughput of the drop-in adapter: N worker threads call rovaca::call_pairhmm on
 // synthetic regions (as haplotypecaller_engine.cpp:119-285 does from its asio pool), through the cross-region batcher.
-// Build: make -C rovaca_amd/host bench   Run on the GPU box: rovaca_amd/lib/adapter_bench [threads] [regions/thread] [reads] [haps]
+// Build: make -C rovaca_amd/host bench   Run on the GPU box: rovaca_amd/lib/adapter_bench [threads] [regions/thread] [reads] [haps] [sw]
+// sw = 1: after PairHMM every surviving read is realigned to its best haplotype through rovaca::sw_hip_align_batch
+// (haplotypecaller_engine.cpp:264), one call per region.
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -11,6 +13,7 @@
 #include <vector>
 
 #include "../rovaca_amd/host/pairhmm_gpu_engine.h"
+#include "../rovaca_amd/host/sw_gpu_engine.h"
 
 using namespace rovaca;
 
@@ -51,13 +54,14 @@ int main(int argc, char **argv)
 {
     const int threads = argc > 1 ? atoi(argv[1]) : 30, per_thread = argc > 2 ? atoi(argv[2]) : 64;
     const int n_reads = argc > 3 ? atoi(argv[3]) : 48, n_haps = argc > 4 ? atoi(argv[4]) : 9;
+    const bool with_sw = argc > 5 && atoi(argv[5]) != 0;
     if (!init_pairhmm_ptr_gpu(0)) {
         fprintf(stderr, "no MI355X visible\n");
         return 2;
     }
     std::vector<Region> regions;
     for (int i = 0; i < 16; ++i) regions.push_back(make_region(1000 + i, n_reads, n_haps, 150, 300));
-    std::atomic<uint64_t> cells{0}, kept{0};
+    std::atomic<uint64_t> cells{0}, kept{0}, sw_cells{0}, sw_elems{0};
     auto work = [&](int t) {
         for (int k = 0; k < per_thread; ++k) {
             Region &rg = regions[(t + k) % regions.size()];
@@ -69,10 +73,30 @@ int main(int argc, char **argv)
             DoubleVector2D lik = call_pairhmm(hs, rs, 18, PcrIndelModel::CONSERVATIVE, &arena);
             cells += rg.cells;
             kept += rs.size();
+            if (with_sw && !rs.empty()) {
+                std::vector<std::vector<uint8_t>> seqs(rs.size());
+                std::vector<SwJob> jobs(rs.size());
+                for (size_t r = 0; r < rs.size(); ++r) {
+                    size_t best = 0;
+                    for (size_t h = 1; h < hs.size(); ++h)
+                        if (lik[h][r] > lik[best][r]) best = h;
+                    seqs[r].resize(sizeof(Bases) + (size_t)rs[r]->seq_length() + 1);
+                    pBases b = reinterpret_cast<pBases>(seqs[r].data());
+                    rs[r]->decode_base(b);
+                    const pBases hap = hs[best]->get_display_string();
+                    jobs[r] = SwJob{hap->data, (int32_t)hap->num, b->data, (int32_t)b->num};
+                    sw_cells += (uint64_t)hap->num * b->num;
+                }
+                std::vector<SwAlignment> aln;
+                const sw_parameters genotype{10, -15, -30, -5};  // sw_avx.c:14
+                if (!sw_hip_align_batch(jobs.data(), jobs.size(), genotype, aln)) exit(3);
+                sw_elems += aln.empty() ? 0 : aln[0].cigar.size();
+            }
         }
     };
     work(0);  // warm up: contexts, tables, kernels
     cells = 0;
+    sw_cells = 0;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
@@ -81,8 +105,9 @@ int main(int argc, char **argv)
     uint64_t nreg = 0, nsub = 0;
     gpu_pairhmm_batching_stats(&nreg, &nsub);
     printf("{\"threads\": %d, \"regions\": %d, \"reads_per_region\": %d, \"haps_per_region\": %d, \"seconds\": %.4f, "
-           "\"regions_per_s\": %.0f, \"gcups_end_to_end\": %.1f, \"device_submissions\": %llu, \"regions_per_submission\": %.1f}\n",
+           "\"regions_per_s\": %.0f, \"gcups_end_to_end\": %.1f, \"device_submissions\": %llu, \"regions_per_submission\": %.1f, "
+           "\"smith_waterman\": %s, \"sw_gcups_end_to_end\": %.1f}\n",
            threads, threads * per_thread, n_reads, n_haps, sec, threads * per_thread / sec, cells.load() / sec / 1e9,
-           (unsigned long long)nsub, nsub ? (double)nreg / nsub : 0.0);
+           (unsigned long long)nsub, nsub ? (double)nreg / nsub : 0.0, with_sw ? "true" : "false", sw_cells.load() / sec / 1e9);
     return 0;
 }
