@@ -168,6 +168,7 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
 
     // ---- classify: (lanes per alignment, columns per lane); longest reference first inside a launch ----
     constexpr uint64_t kWideMaxPairs = 2048;
+    constexpr uint32_t kLdsFlagsMaxPairs = 768;  // 256 CUs x up to 3 workgroups of ~50 KB
     int forced_lanes = 0;
     if (const char *e = getenv("SWHIP_FORCE_LANES")) forced_lanes = atoi(e);  // tests
     std::vector<uint64_t> keys;  // class << 48 | (0xFFFF - len1) << 32 | pair
@@ -295,6 +296,11 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
         a.order = reinterpret_cast<const uint32_t *>(base + o_order) + l.first;
         a.n_pairs = l.count;
         a.lds_stride = (l.max_len1 + 15u) & ~15u;
+        // small one-alignment-per-wave launches keep their flags in LDS: the traceback then waits ~100 cycles per step, not ~700
+        const uint64_t bt_bytes = swhip::bt_words(l.max_len1, l.lanes, l.k) * 4;
+        const bool in_lds = l.lanes == 64 && l.count <= kLdsFlagsMaxPairs && a.lds_stride + bt_bytes <= 150u * 1024u && !getenv("SWHIP_NO_LDS_FLAGS");
+        a.bt_in_lds = in_lds ? 1u : 0u;
+        a.lds_bt_bytes = in_lds ? (uint32_t)bt_bytes : 0u;
         HIP_TRY(swhip::launch_sw(l.k, l.lanes, a, st));
     }
     HIP_TRY(hipEventRecord(c->ev1, st));

@@ -45,6 +45,8 @@ struct SwArgs
     const uint32_t *order;      // pairs of this launch, in processing order
     uint32_t n_pairs;
     uint32_t lds_stride;        // bytes of LDS per alignment: the longest seq1 of the launch, rounded up
+    uint32_t bt_in_lds;         // 1: backtrack flags live in LDS (lds_bt_bytes behind seq1), one alignment per workgroup
+    uint32_t lds_bt_bytes;
     int32_t w_match, w_mismatch, w_open, w_extend;
     uint32_t *bt;               // backtrack flags; pair p starts at bt_off[p] (see bt_words)
     const uint64_t *bt_off;

@@ -53,15 +53,17 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     // 5 bytes per step instead of 8
     constexpr uint32_t W32 = K / 8, TAILB = bt_tail_bytes(K);
     const uint32_t lane = threadIdx.x & (G - 1);
-    const uint32_t gidx = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const uint32_t gidx = blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
     const bool valid = gidx < a.n_pairs;
     const uint32_t pair = a.order[valid ? gidx : 0];
     const uint32_t r = a.pair_ref[pair], s = a.pair_seq[pair];
     const int32_t nrow = (int32_t)a.ref_len[r], ncol = (int32_t)a.seq_len[s];
     const uint8_t *__restrict__ s1 = a.ref_bases + a.ref_off[r];
     const uint8_t *__restrict__ s2 = a.seq_bases + a.seq_off[s];
-    uint32_t *__restrict__ bt = a.bt + a.bt_off[pair];
-    uint8_t *__restrict__ bt_tail = reinterpret_cast<uint8_t *>(bt + (size_t)(nrow + G - 1) * G * (K / 8));
+    // backtrack flags: global memory, or -- for small batches, where the traceback's dependent loads are what the call waits
+    // for -- the workgroup's LDS behind seq1 (one alignment per workgroup then)
+    uint32_t *bt = a.bt_in_lds ? reinterpret_cast<uint32_t *>(lds_seq1 + (blockDim.x / G) * a.lds_stride) : a.bt + a.bt_off[pair];
+    uint8_t *bt_tail = reinterpret_cast<uint8_t *>(bt + (size_t)(nrow + G - 1) * G * (K / 8));
     int32_t *__restrict__ lastcol = a.scratch + a.scratch_off[pair];  // [i-1]: H[i][ncol]
     int32_t *__restrict__ lastrow = lastcol + nrow;                    // [j-1]: H[nrow][j]
     uint32_t *__restrict__ elems = reinterpret_cast<uint32_t *>(lastrow + ncol);
@@ -329,9 +331,16 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
 template <int K, int G>
 static hipError_t launch_one(const SwArgs &a, hipStream_t s)
 {
-    const uint32_t per_block = kBlockThreads / G;
+    const uint32_t threads = a.bt_in_lds ? (uint32_t)G : (uint32_t)kBlockThreads;  // LDS-resident flags: one alignment per workgroup
+    const uint32_t per_block = threads / G;
     const uint32_t blocks = (a.n_pairs + per_block - 1) / per_block;
-    hipLaunchKernelGGL((sw_kernel<K, G>), dim3(blocks), dim3(kBlockThreads), (size_t)per_block * a.lds_stride, s, a);
+    const size_t shmem = (size_t)per_block * a.lds_stride + (a.bt_in_lds ? a.lds_bt_bytes : 0u);
+    if (shmem > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_kernel<K, G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((sw_kernel<K, G>), dim3(blocks), dim3(threads), shmem, s, a);
     return hipGetLastError();
 }
 
@@ -343,7 +352,7 @@ int pick_cols_per_lane(uint32_t len2, int lanes_per_pair)
             if ((uint32_t)k >= need) return k;
         return 0;
     }
-    for (int k : {4, 8, 16, 32})
+    for (int k : {2, 3, 4, 8, 16, 32})
         if ((uint32_t)k >= need) return k;
     return 0;
 }
@@ -366,6 +375,8 @@ hipError_t launch_sw(int cols_per_lane, int lanes_per_pair, const SwArgs &a, hip
     }
     if (lanes_per_pair == 64) {
         switch (cols_per_lane) {
+            case 2: return launch_one<2, 64>(a, s);
+            case 3: return launch_one<3, 64>(a, s);
             case 4: return launch_one<4, 64>(a, s);
             case 8: return launch_one<8, 64>(a, s);
             case 16: return launch_one<16, 64>(a, s);

@@ -105,9 +105,12 @@ def test_backtrack_memory_is_reused_across_launches(aligner, monkeypatch):
     assert st.n_launches > 3
 
 
-@pytest.mark.parametrize("lanes", [16, 64])
-def test_every_geometry_and_long_sequences(aligner, lanes, monkeypatch):
+@pytest.mark.parametrize("lanes,lds_flags", [(16, False), (64, False), (64, True)])
+def test_every_geometry_and_long_sequences(aligner, lanes, lds_flags, monkeypatch):
+    # both shapes; with one alignment per wave the backtrack flags live in LDS for small batches, in global memory otherwise
     monkeypatch.setenv("SWHIP_FORCE_LANES", str(lanes))
+    if not lds_flags:
+        monkeypatch.setenv("SWHIP_NO_LDS_FLAGS", "1")
     # seq2 lengths across every columns-per-lane instantiation of both shapes (16 and 64 lanes per alignment)
     rng = np.random.default_rng(9)
     acgt = np.frombuffer(b"ACGT", np.uint8)
