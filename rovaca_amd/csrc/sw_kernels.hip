@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sw_device.h"
 
 namespace swhip
@@ -101,17 +103,24 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     }
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
 
+    // the scoring constants as VGPRs once (the cell's assembly wants registers; left alone the compiler re-materialises them
+    // from SGPRs every step)
+    uint32_t vw_match = w_match, vw_mismatch = w_mismatch, vw_open = w_open, vw_extend = w_extend;
+    asm volatile("" : "+v"(vw_match), "+v"(vw_mismatch), "+v"(vw_open), "+v"(vw_extend));
+
     uint32_t next1 = (valid && lane == 0) ? (uint32_t)my1[0] : 0u;  // seq1 base of the row this lane does next
-    for (int32_t t = 1; t <= Tmax; ++t) {
+    // One step.  `steady` = every lane of the wave is inside its alignment and none is on its last row: no predicate, no
+    // last-row capture, the next base is always there.
+    auto step = [&](int32_t t, auto steady) {
         const int32_t i = t - (int32_t)lane;  // this lane's row
-        const bool active = valid && i >= 1 && i <= nrow;
+        const bool active = steady || (valid && i >= 1 && i <= nrow);
         const uint32_t diag0 = inH;           // H[i-1][jL]: what came in one step ago
         inH = (uint32_t)shr1<G>((int32_t)inH, (int32_t)outH);
         inE = (uint32_t)shr1<G>((int32_t)inE, (int32_t)outE);
         const uint32_t base1 = next1;
         {
             const int32_t ni = i + 1;  // prefetch the base of the next row while this one is computed
-            next1 = (valid && ni >= 1 && ni <= nrow) ? (uint32_t)my1[ni - 1] : 0u;
+            next1 = (steady || (valid && ni >= 1 && ni <= nrow)) ? (uint32_t)my1[ni - 1] : 0u;
         }
         if (active) {
             uint32_t hl = inH, e = inE, hd = diag0, h_ncol = 0;
@@ -156,7 +165,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                       [openh] "=&v"(t_openh), [sc] "=&v"(t_sc), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv),
                       [h1] "=&v"(t_h1)
                     : [b1] "v"(base1), [b2] "v"(base2[k]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [hp] "v"(Hp[k]),
-                      [wext] "v"(w_extend), [wopen] "v"(w_open), [wm] "v"(w_match), [wmm] "v"(w_mismatch)
+                      [wext] "v"(vw_extend), [wopen] "v"(vw_open), [wm] "v"(vw_match), [wmm] "v"(vw_mismatch)
                     : "vcc");
                 words[k / 8] = acc;
                 hd = Hp[k];  // the diagonal of the next column
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 if constexpr (TAILB == 4) reinterpret_cast<uint32_t *>(bt_tail)[slot] = words[W - 1];
             }
             if (lane == lc) lastcol[i - 1] = (int32_t)(h_ncol - kBias);  // column ncol, every row
-            if (i == nrow) {  // row nrow, every column
+            if (!steady && i == nrow) {  // row nrow, every column
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int32_t j = (int32_t)lane * K + k + 1;
@@ -186,7 +195,18 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 }
             }
         }
+    };
+    // fill (lanes join one by one), steady, drain (lanes and shorter alignments leave)
+    int32_t Tsteady = valid ? nrow - 1 : 0;  // last step at which every lane of this alignment is below its last row
+    if (G == 16) {
+        Tsteady = min(Tsteady, __shfl_xor(Tsteady, 16));
+        Tsteady = min(Tsteady, __shfl_xor(Tsteady, 32));
     }
+    Tsteady = __builtin_amdgcn_readfirstlane(Tsteady);
+    int32_t t = 1;
+    for (; t < G && t <= Tmax; ++t) step(t, std::false_type{});
+    for (; t <= Tsteady; ++t) step(t, std::true_type{});
+    for (; t <= Tmax; ++t) step(t, std::false_type{});
     __threadfence_block();  // this lane's own stores are visible to the loads below (same work-item or same wave)
     __syncthreads();
 
