@@ -66,3 +66,45 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
 print("\n".join(lines))
 for c in stats:
     print(c, [(r["Name"][:60], r["Calls"], r["AverageNs"]) for r in stats[c][:4]])
+
+
+# ---- Smith-Waterman aligner (tools/bench_sw.py) ----
+f = os.path.join(src, "trace_sw", "sw_kernel_stats.csv")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(dst, "%s_kernel_stats.csv" % tag.replace("final", "sw")))
+    rows = list(csv.DictReader(open(f)))
+    hot = next(r for r in rows if "sw_kernel" in r["Name"])
+    mean = {}
+    for g in glob.glob(os.path.join(src, "pmcsw_*", "pmc_counter_collection.csv")):
+        c = {}
+        for r in csv.DictReader(open(g)):
+            if "sw_kernel" in r["Kernel_Name"]:
+                c.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+                c[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for k, v in c.items():
+            mean[k] = sum(v.values()) / len(v)
+    ms = float(hot["AverageNs"]) / 1e6
+    m = re.search(r'"gpu_kernel_ms": ([0-9.]+)', open(os.path.join(src, "bench_sw.log")).read())
+    valu, waves = mean.get("SQ_INSTS_VALU", 0.0), mean.get("SQ_WAVES", 1.0)
+    txt = [
+        "rocprofv3 on `python3 tools/bench_sw.py --regions 1000 --no-cpu` (48 000 read-vs-haplotype alignments, 150-153 x 400, genotype",
+        "parameters) on MI355X (tools/profile_round.sh).  kernel: %s (16 lanes per alignment, 10 columns per lane)." % hot["Name"],
+        "kernel-trace (profiles/%s_kernel_stats.csv): average %.3f ms, min %.3f ms; HIP events inside swhip_align in that run: %s ms."
+        % (tag.replace("final", "sw"), ms, float(hot["MinNs"]) / 1e6, m.group(1) if m else "?"),
+        "PMC passes (separate runs), per launch:",
+        "  ".join("%s %.4g" % (k, mean[k]) for k in sorted(mean)),
+    ]
+    if valu:
+        txt += [
+            "derived: %.0f VALU wave-instructions per wave = %.0f per sweep step (400 + 15 steps, 10 cells per lane per step: %.1f per cell"
+            % (valu / waves, valu / waves / 415, valu / waves / 4150),
+            "         including end-cell search and traceback); over %.2f ms at 2.05 GHz the 1 024 SIMDs spend %.2f cycles per VALU"
+            % (ms, ms * 1e-3 * 2.05e9 * 1024 / valu),
+            "         instruction; tools/ubench_valu.hip measures 2.7 for v_add_u32 and 2.55 for compare/select/add-with-carry through VCC.",
+        ]
+    if "WRITE_SIZE" in mean:
+        txt += ["bound: integer VALU.  HBM traffic is the backtrack flags (4 bits per cell): %.2f GB written per launch = %.2f TB/s, %.0f %% of 8 TB/s;"
+                % (mean["WRITE_SIZE"] * 1024 / 1e9, mean["WRITE_SIZE"] * 1024 / ms / 1e9, 100 * mean["WRITE_SIZE"] * 1024 / ms / 1e9 / 8),
+                "       the algorithmic input/output (len1 + len2 in, 20 B + CIGAR out, ~0.6 KB per alignment) is 0.2 % of HBM."]
+    open(os.path.join(dst, "%s_pmc_summary.txt" % tag.replace("final", "sw")), "w").write("\n".join(txt) + "\n")
+    print("\n".join(txt))
