@@ -11,48 +11,48 @@
 extern "C" {
 #endif
 
+/* scoring constants of one handle (two sets exist: assembly and genotyping) */
 typedef struct sw_parameters_t {
-    int32_t match;
-    int32_t mismatch;
-    int32_t gap_open;
-    int32_t gap_extend;
+    int32_t match, mismatch, gap_open, gap_extend;
 } sw_parameters;
 
+/* The handle.  Only the members marked [in] / [out] are touched by the GPU candidate; the rest is the AVX
+ * implementation's private state and is kept solely so that offsets agree with the reference's definition. */
 typedef struct lib_sw_avx_st {
-    uint8_t *seq1;  // ref
-    uint8_t *seq2;  // seq
-    int16_t len1;
-    int16_t len2;
-    int32_t score;
-    int16_t max_i;
-    int16_t max_j;
-    int16_t *btrack;
-    uint32_t *cigar;
-    uint32_t cigar_count;
-    uint32_t cigar_max_len;
-    int16_t alignment_offset;
+    uint8_t *seq1; /* [in]  rows: haplotype / padded reference */
+    uint8_t *seq2; /* [in]  columns: read / haplotype path */
+    int16_t len1;  /* [in]  */
+    int16_t len2;  /* [in]  */
+    int32_t score; /* [out] best end-cell score */
+    int16_t max_i; /* [out] row of the best end cell */
+    int16_t max_j; /* [out] column of the best end cell */
+    int16_t *btrack;        /* AVX: backtrack matrix */
+    uint32_t *cigar;        /* [out] BAM elements, first to last */
+    uint32_t cigar_count;   /* [out] */
+    uint32_t cigar_max_len; /* [in]  capacity of cigar[] */
+    int16_t alignment_offset; /* [out] rows of seq1 before the alignment starts; 1 when nothing was aligned */
 
-    int32_t max_seq_len;
+    int32_t max_seq_len; /* [in]  length limit (2048) */
     int32_t seq_len_changed;
 
-    struct {
+    struct { /* AVX: aligned work buffers */
         int32_t *e;
         int16_t *back_track;
         int16_t *cigar_buf;
     } mm_aloc;
 
-    sw_parameters para;
+    sw_parameters para; /* [in] */
 
     uint32_t data_len;
     uint32_t max_data_len;
 
-    struct {
+    struct { /* AVX: widened copies of the sequences */
         uint32_t *seq1_rev;
         uint32_t *seq2;
     } cacl_cache;
-    void (*avx_function)(struct lib_sw_avx_st *p);
+    void (*avx_function)(struct lib_sw_avx_st *p); /* the seam: bound once, called per alignment */
 
-    uint8_t data[];
+    uint8_t data[]; /* storage the pointers above point into */
 } lib_sw_avx, *p_lib_sw_avx;
 
 #ifdef __cplusplus
