@@ -83,3 +83,19 @@ double ref_sw_batch(int is_assemble, const uint8_t *ref_bases, const uint32_t *r
     if (checksum) *checksum = sum;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* layout of the REAL handle (smithwaterman_common.h), for tests/test_capi_cpu.py to compare with the adapter's mirror */
+#include <stddef.h>
+int ref_sw_layout(int32_t *out, int cap)
+{
+    const int32_t v[] = {(int32_t)sizeof(lib_sw_avx),
+                         (int32_t)offsetof(lib_sw_avx, seq1), (int32_t)offsetof(lib_sw_avx, seq2), (int32_t)offsetof(lib_sw_avx, len1),
+                         (int32_t)offsetof(lib_sw_avx, len2), (int32_t)offsetof(lib_sw_avx, score), (int32_t)offsetof(lib_sw_avx, max_i),
+                         (int32_t)offsetof(lib_sw_avx, max_j), (int32_t)offsetof(lib_sw_avx, cigar), (int32_t)offsetof(lib_sw_avx, cigar_count),
+                         (int32_t)offsetof(lib_sw_avx, cigar_max_len), (int32_t)offsetof(lib_sw_avx, alignment_offset),
+                         (int32_t)offsetof(lib_sw_avx, max_seq_len), (int32_t)offsetof(lib_sw_avx, para),
+                         (int32_t)offsetof(lib_sw_avx, avx_function), (int32_t)offsetof(lib_sw_avx, data)};
+    const int n = (int)(sizeof(v) / sizeof(v[0]));
+    for (int k = 0; k < n && k < cap; ++k) out[k] = v[k];
+    return n;
+}

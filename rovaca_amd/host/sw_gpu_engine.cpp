@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -246,6 +247,21 @@ int sw_hip_install(p_lib_sw_avx p)
     swhip_destroy(probe);
     p->avx_function = sw_hip_run;
     return 1;
+}
+
+// layout of the handle as this library sees it (tests compare it with the reference's own header where that is available)
+int rovaca_amd_sw_layout(int32_t *out, int cap)
+{
+    const int32_t v[] = {(int32_t)sizeof(lib_sw_avx),
+                         (int32_t)offsetof(lib_sw_avx, seq1), (int32_t)offsetof(lib_sw_avx, seq2), (int32_t)offsetof(lib_sw_avx, len1),
+                         (int32_t)offsetof(lib_sw_avx, len2), (int32_t)offsetof(lib_sw_avx, score), (int32_t)offsetof(lib_sw_avx, max_i),
+                         (int32_t)offsetof(lib_sw_avx, max_j), (int32_t)offsetof(lib_sw_avx, cigar), (int32_t)offsetof(lib_sw_avx, cigar_count),
+                         (int32_t)offsetof(lib_sw_avx, cigar_max_len), (int32_t)offsetof(lib_sw_avx, alignment_offset),
+                         (int32_t)offsetof(lib_sw_avx, max_seq_len), (int32_t)offsetof(lib_sw_avx, para),
+                         (int32_t)offsetof(lib_sw_avx, avx_function), (int32_t)offsetof(lib_sw_avx, data)};
+    const int n = (int)(sizeof(v) / sizeof(v[0]));
+    for (int k = 0; k < n && k < cap; ++k) out[k] = v[k];
+    return n;
 }
 
 // Test shim (plain C types for ctypes): builds a handle the way sw_avx_init lays it out (sw_avx.c:401-437, buffers only as

@@ -74,3 +74,16 @@ def test_sw_host_adapter_exports_the_seam_candidates():
     L = ctypes.CDLL(os.path.join(ROOT, "rovaca_amd", "lib", "librovaca_sw_host.so"))
     for n in ("sw_hip_run", "sw_hip_install", "rovaca_amd_sw_run_through_handle"):
         assert hasattr(L, n)
+
+
+def test_sw_handle_mirror_has_the_reference_layout():
+    # rovaca_amd/host/sw_seam.h restates lib_sw_avx; where the reference's header is available (oracle/_ref) the offsets of
+    # every member the adapter touches must agree with it
+    import oracle
+    ref = oracle.sw_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref/libsw_ref.so not available")
+    L = ctypes.CDLL(os.path.join(ROOT, "rovaca_amd", "lib", "librovaca_sw_host.so"))
+    a, b = (ctypes.c_int32 * 32)(), (ctypes.c_int32 * 32)()
+    na, nb = L.rovaca_amd_sw_layout(a, 32), ref.ref_sw_layout(b, 32)
+    assert na == nb == 16 and list(a[:na]) == list(b[:nb])
