@@ -158,7 +158,7 @@ def main():
                        "parallelism": f"pair-split x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "pairhmm_systolic_kernel<float,K,UG>", "kernel_ms": round(k_ms, 4),
+                         "kernel": "pairhmm_systolic_kernel<float,K,UG,G>", "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes": alg_bytes},
             "roofline_valu": {"bound": "fp32-valu", "achieved": round(valu_tflops, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(valu_tflops / FP32_VALU_PEAK_TFLOPS, 5),
