@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "sw"],
+                    help="c1..c5: BASELINE configs of the PairHMM path; sw: the Smith-Waterman realignment next to it (SURVEY 8f next-4)")
+    ap.add_argument("--sw-regions", type=int, default=1000, help="--config sw: regions of 48 reads (150 bp) against 400-bp haplotypes")
     ap.add_argument("--scale", type=float, default=1.0, help="multiplies the number of regions of the config")
     ap.add_argument("--chunk-regions", type=int, default=1000, help="regions per resident chunk (c4 streams 12.5 chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -60,6 +62,9 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(device)
+
+    if args.config == "sw":
+        return bench_smith_waterman(args, rank, world, device, dist)
 
     from rovaca_amd import capi, synth
 
@@ -177,6 +182,100 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def bench_smith_waterman(args, rank, world, device, dist):
+    """--config sw: every read of a region against its best haplotype, the genotyping call site of the reference's
+    Smith-Waterman (alignment_utils.cpp:572-579).  A step is one swhip_align call on the batch; value = cells all ranks
+    aligned / max wall time of the device launches (HIP events inside the call).  The batch is host memory here (the C ABI
+    takes host buffers), so the PCIe-inclusive rate of the whole call is reported beside it."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from rovaca_amd import swapi
+
+    rng = np.random.default_rng(5 + 1000 * rank)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    refs, seqs, pairs = [], [], []
+    for region in range(args.sw_regions):
+        base = acgt[rng.integers(0, 4, 400)]
+        haps = []
+        for h in range(4):
+            hap = base.copy()
+            for _ in range(h):
+                hap[int(rng.integers(0, len(hap)))] = acgt[rng.integers(0, 4)]
+            haps.append(hap)
+        h0 = len(refs)
+        refs += haps
+        for r in range(48):
+            hap = haps[r % 4]
+            a = int(rng.integers(0, len(hap) - 150 + 1))
+            read = hap[a:a + 150].copy()
+            read[rng.random(len(read)) < 0.01] = ord("C")
+            if r % 6 == 0:
+                k = int(rng.integers(1, len(read) - 1))
+                read = np.concatenate([read[:k], acgt[rng.integers(0, 4, 3)], read[k:]])
+            seqs.append(read)
+            pairs.append((h0 + r % 4, len(seqs) - 1))
+    al = swapi.Aligner(device)
+    for _ in range(max(1, args.warmup)):
+        out, cig, st = al.align(refs, seqs, pairs)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_s, call_s = 0.0, 0.0
+    for _ in range(args.steps):
+        out, cig, st = al.align(refs, seqs, pairs)
+        kernel_s += st.kernel_ms * 1e-3
+        call_s += st.total_ms * 1e-3
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([kernel_s, call_s], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_s, call_s = float(t[0]), float(t[1])
+    if rank != 0:
+        return
+    cells = int(st.cells)
+    gcups = world * cells * args.steps / kernel_s / 1e9
+    alg_bytes = sum(len(refs[a]) + len(seqs[b]) + 20 for a, b in pairs) + 4 * len(cig)
+    res = {
+        "metric": "Smith-Waterman GCUPS", "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(kernel_s / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "sw: %d alignments/GPU, reads 150-153 bp against 400-bp haplotypes, genotype parameters "
+                               "(10, -15, -30, -5), traceback and CIGAR on the device" % len(pairs),
+                   "alignments_per_gpu": len(pairs), "cells_per_gpu": cells, "parallelism": f"alignment-split x{world}, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(alg_bytes * args.steps / kernel_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg_bytes * args.steps / kernel_s / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                     "kernel": "swhip::sw_kernel<K,G>", "kernel_ms": round(kernel_s / args.steps * 1e3, 4),
+                     "algorithmic_bytes": alg_bytes,
+                     "note": "integer-VALU bound (DESIGN.md 7); the backtrack flags (4 bits per cell) are the HBM traffic"},
+        "call_gcups_pcie_inclusive": round(world * cells * args.steps / call_s / 1e9, 2),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle  # checker + CPU baseline leg only
+
+        for p in rng.choice(len(pairs), 200, replace=False):
+            o = oracle.sw_align(refs[pairs[p][0]], seqs[pairs[p][1]])
+            assert (int(out[p]["score"]), int(out[p]["alignment_offset"])) == (o["score"], o["alignment_offset"])
+            assert np.array_equal(swapi.cigar_of(out[p], cig), o["cigar"])
+        res["parity_sample"] = "200 alignments bit-identical to the CPU restatement (score, offset, CIGAR)"
+        if oracle.sw_ref() is not None:
+            rb, ro, rl = swapi._tables(refs)
+            sb, so, sl = swapi._tables(seqs)
+            pr = np.ascontiguousarray([p[0] for p in pairs], np.uint32)
+            ps = np.ascontiguousarray([p[1] for p in pairs], np.uint32)
+            n = min(len(pairs), 20000)
+            chk = C.c_int64()
+            sec = oracle.sw_ref().ref_sw_batch(0, rb, ro, rl, sb, so, sl, pr[:n].copy(), ps[:n].copy(), n, 1, C.byref(chk))
+            ccells = int(sum(int(rl[pr[k]]) * int(sl[ps[k]]) for k in range(n)))
+            res["cpu_baseline"] = {"value": round(ccells / sec / 1e9, 3), "unit": "GCUPS", "cores": 1, "kind": "reference",
+                                   "sample": "%d alignments through the reference's sw_avx.c (function chosen by sw_avx_init) on "
+                                             "one thread, %.2f s" % (n, sec)}
+    print(json.dumps(res))
 
 
 def cpu_baseline(batch, gpu_raw, gpu_l10, threads):

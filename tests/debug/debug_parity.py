@@ -1,14 +1,14 @@
 """Print per-pair mismatches of the HIP path vs the oracle on a few batches (debug aid; run on the GPU box)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from rovaca_amd import capi, synth
 from rovaca_amd.batch import Batch
 
 eng = capi.Engine(0)
 g = dict(np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "pairhmm_golden.npz")))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from conftest import golden_batch
 for tag in ("edge", "c1", "c3", "noisy"):
     b = golden_batch(g, tag)

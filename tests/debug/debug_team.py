@@ -1,7 +1,7 @@
 """Compare the team kernel against the oracle on a few long-read pairs, per forced shape (debug aid; run on the GPU box)."""
 import os, sys, subprocess
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 if len(sys.argv) == 1:
     for lanes in ("16", "64"):
         for waves in ("1", "4"):

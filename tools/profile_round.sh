@@ -14,11 +14,11 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   echo "pmc $grp done"
 done
 find $OUT -name "*.csv" | head -30
-# Smith-Waterman aligner: kernel trace of tools/bench_sw.py
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sw -o sw -- python3 tools/bench_sw.py --regions 1000 --no-cpu > $OUT/bench_sw.log 2>&1
+# Smith-Waterman aligner: kernel trace of bench.py --config sw
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sw -o sw -- python3 bench.py --config sw --no-cpu-baseline > $OUT/bench_sw.log 2>&1
 tail -1 $OUT/bench_sw.log | cut -c1-200
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-24)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcsw_$tag -o pmc -- python3 tools/bench_sw.py --regions 1000 --no-cpu --iters 2 > $OUT/pmcsw_$tag.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcsw_$tag -o pmc -- python3 bench.py --config sw --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmcsw_$tag.log 2>&1
 done
 echo "pmc sw done"
