@@ -447,7 +447,12 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
         }
         Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
-        const uint32_t Bs = (Tmax + 31u) / 32u;                // supersteps per stripe
+        // Supersteps per stripe.  With several waves the stripes of a pair chase each other around the team: wave 0 starts
+        // its next stripe Bs supersteps after the previous one, and that stripe reads the carry of the one wave WP-1 is still
+        // sweeping, which started kLag * (WP - 1) supersteps after wave 0 did.  A haplotype shorter than kLag * WP * 32
+        // columns (the team shape is chosen for the longest of the launch) gets idle supersteps, or the carry would be read
+        // before it is written.
+        const uint32_t Bs = max((Tmax + 31u) / 32u, WP > 1 ? kLag * (uint32_t)WP : 1u);
         const uint32_t n_rounds = (max_stripes + WP - 1) / WP;  // stripes per wave
         const uint32_t n_super = n_rounds * Bs + kLag * (WP - 1);  // supersteps of this batch of pairs
         const uint32_t wmax = W - 2;

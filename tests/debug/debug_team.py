@@ -14,7 +14,7 @@ from rovaca_amd.batch import Batch
 rng = np.random.default_rng(8)
 acgt = np.frombuffer(b"ACGT", np.uint8)
 reads, haps, pairs = [], [], []
-for R, H in [(257, 300), (300, 700), (513, 600), (600, 1500), (1025, 1100), (1537, 2000), (2000, 2100), (129, 5000), (40, 4097), (64, 900), (700, 90)]:
+for R, H in [(257, 300), (300, 700), (513, 600), (600, 1500), (1025, 1100), (1537, 2000), (2000, 2100), (129, 5000), (40, 4097), (64, 900), (700, 90), (1745, 314), (1745, 314), (900, 200), (2500, 100)]:
     hap = acgt[rng.integers(0, 4, H)]
     st = int(rng.integers(0, max(1, H - R + 1)))
     seq = np.resize(hap[st:st + R], R).copy()

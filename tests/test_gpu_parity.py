@@ -284,6 +284,23 @@ def test_team_kernel_every_width(engine, waves, lanes, monkeypatch):
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
+def test_team_pipeline_with_a_haplotype_shorter_than_the_pipeline(engine):
+    # found by tests/debug/fuzz_gpu.py: the team shape (waves per pair) is chosen for the longest haplotype of the launch; a
+    # pair of the same launch whose haplotype is shorter than lag * waves * 32 columns must still see its carry written
+    # before it is read (the kernel pads its stripes with idle supersteps)
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    haps = [acgt[rng.integers(0, 4, n)] for n in (4800, 314, 90, 700)]
+    reads = []
+    for R in (1745, 2500, 900, 400):
+        seq = acgt[rng.integers(0, 4, R)]
+        q = rng.integers(6, 41, R).astype(np.uint8)
+        g = np.full(R, 40, np.uint8)
+        reads.append((seq, q, g, g, np.full(R, 10, np.uint8)))
+    pairs = [(r, h) for r in range(4) for h in range(4)] * 3
+    _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
+
+
 def test_symbols_outside_ACGTN_never_match(engine):
     # pairhmm_internal.cpp:27-41: lower case, IUPAC codes, '-' ... map to code 0 and match nothing, not even themselves
     rng = np.random.default_rng(31)
