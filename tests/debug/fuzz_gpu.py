@@ -44,9 +44,17 @@ while time.time() < t_end:
             gi = gd = rng.choice(np.array([45, 40, 35], np.uint8), R)
             gc = np.full(R, 10, np.uint8)
         reads.append((seq, q, gi, gd, gc))
-    pairs = [(int(rng.integers(0, n_reads)), int(rng.integers(0, n_haps))) for _ in range(int(rng.integers(1, 200)))]
+    big = mode < 2 and it % 7 == 0  # now and then a launch big enough for the four-pairs-per-wave shapes
+    pairs = [(int(rng.integers(0, n_reads)), int(rng.integers(0, n_haps))) for _ in range(int(rng.integers(2000, 7000) if big else rng.integers(1, 200)))]
     b = Batch.from_lists(reads, haps, pairs)
-    raw, l10, st = eng.compute(b)
+    if it % 3 == 0:  # resident path: upload once, sweep twice, download
+        rb = eng.upload(b)
+        rb.sweep()
+        rb.sweep()
+        raw, l10, st = rb.download()
+        rb.release()
+    else:
+        raw, l10, st = eng.compute(b)
     oraw, ol10, oresc = oracle.batch(b, n_threads=8)
     if not np.array_equal(raw.view(np.uint32), oraw.view(np.uint32)):
         bad = np.nonzero(raw.view(np.uint32) != oraw.view(np.uint32))[0]
@@ -68,7 +76,8 @@ while time.time() < t_end:
     lim = int(rng.choice([40, 300, 700, 2047]))
     refs = [acgt[rng.integers(0, 4, int(rng.integers(1, lim + 1)))] for _ in range(n_ref)]
     seqs, sp = [], []
-    for _ in range(int(rng.integers(1, 40))):
+    big_sw = it % 11 == 0 and lim <= 300
+    for _ in range(int(rng.integers(2100, 3000) if big_sw else rng.integers(1, 40))):
         ref = refs[int(rng.integers(0, n_ref))]
         n = int(rng.integers(1, min(len(ref), lim) + 1))
         if rng.random() < 0.8:
@@ -95,3 +104,37 @@ while time.time() < t_end:
     if it % 20 == 0:
         print(f"iter {it}: {n_ph} pairhmm pairs, {n_sw} alignments ok", flush=True)
 print(f"fuzz ok: {it} iterations, {n_ph} PairHMM pairs, {n_sw} Smith-Waterman alignments, seed {seed}")
+
+# ---- the drop-in adapter (rovaca::call_pairhmm through the C shim) against the oracle's call_region ----
+from rovaca_amd import hostapi, synth  # noqa: E402
+
+assert hostapi.init_pairhmm_ptr_gpu(0)
+t_end = time.time() + budget / 4
+n_reg = 0
+while time.time() < t_end:
+    n_reg += 1
+    s = int(rng.integers(0, 1 << 30))
+    rl = (int(rng.integers(5, 60)), int(rng.integers(60, 260)))
+    hl = int(rng.integers(rl[1], rl[1] + 300))
+    b = synth.make_batch(seed=s, n_regions=1, reads=int(rng.integers(1, 60)), haps=int(rng.integers(1, 12)), read_len=rl, hap_len=hl,
+                         sub_rate=float(rng.choice([0.0, 0.01, 0.05])))
+    n = b.read_bases.shape[0]
+    qual = rng.choice(np.array([2, 11, 25, 37, 41], np.uint8), n, p=[0.02, 0.05, 0.15, 0.7, 0.08])
+    mq = rng.choice(np.array([60, 60, 60, 29, 12], np.uint8), b.n_reads)
+    bases = b.read_bases.copy()
+    for r in rng.choice(b.n_reads, min(b.n_reads, int(rng.integers(0, 4))), replace=False):
+        o, L = int(b.read_off[r]), int(b.read_len[r])
+        bases[o:o + L] = acgt[rng.integers(0, 4, L)]
+    model = str(rng.choice(["NONE", "CONSERVATIVE", "HOSTILE", "AGGRESSIVE"]))
+    minq = int(rng.choice([6, 18, 30]))
+    got, surv = hostapi.call_region(bases, qual, b.read_off, b.read_len, mq, b.hap_bases, b.hap_off, b.hap_len, min_quality_threshold=minq,
+                                    pcr_model=model)
+    want = np.full(b.n_haps * b.n_reads, np.nan)
+    wsurv = np.zeros(b.n_reads, np.uint32)
+    k = oracle.lib().phmm_oracle_call_region(bases, qual, b.read_off, b.read_len, mq, b.n_reads, b.hap_bases, b.hap_off, b.hap_len, b.n_haps,
+                                             minq, hostapi.PCR[model], want, wsurv)
+    want = want.reshape(b.n_haps, b.n_reads)
+    if not (len(surv) == k and np.array_equal(surv, wsurv[:k]) and np.array_equal(got[:, :k], want[:, :k]) and np.all(np.isnan(got[:, k:]))):
+        print("REGION MISMATCH seed", s, model, minq, b.n_reads, b.n_haps, rl, hl)
+        sys.exit(1)
+print(f"fuzz ok: {n_reg} regions through the adapter")
