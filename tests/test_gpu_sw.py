@@ -178,3 +178,44 @@ def test_drop_in_candidate_through_the_reference_handle():
                 continue
             assert (sc.value, mi.value, mj.value, off.value) == (o["score"], o["max_i"], o["max_j"], o["alignment_offset"])
             assert np.array_equal(cig[:cnt.value], o["cigar"])
+
+
+def test_concurrent_callers_are_batched_and_each_gets_its_own_result():
+    # sw_hip_run -> sw_hip_align_batch -> dispatcher threads that merge concurrent requests into one device call
+    import ctypes as C
+    import threading
+    L = C.CDLL(os.path.join(os.path.dirname(swapi.__file__), "lib", "librovaca_sw_host.so"))
+    i32 = C.POINTER(C.c_int32)
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    L.rovaca_amd_sw_run_through_handle.argtypes = [u8p, C.c_int32, u8p, C.c_int32, C.c_int, i32, i32, i32, i32, u32p, C.c_uint32,
+                                                   C.POINTER(C.c_uint32)]
+    L.rovaca_amd_sw_run_through_handle.restype = C.c_int
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    jobs = []
+    for t in range(64):
+        ref = acgt[rng.integers(0, 4, int(rng.integers(100, 500)))]
+        n2 = int(rng.integers(20, 150))
+        a = int(rng.integers(0, len(ref) - n2))
+        seq = np.ascontiguousarray(ref[a:a + n2].copy())
+        seq[rng.random(n2) < 0.05] = ord("C")
+        jobs.append((np.ascontiguousarray(ref), seq, t % 2))
+    results = [None] * len(jobs)
+
+    def work(lo, hi):
+        for k in range(lo, hi):
+            ref, seq, asm = jobs[k]
+            sc, mi, mj, off, cnt = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint32()
+            cig = np.zeros(len(ref) + len(seq) + 8, np.uint32)
+            rc = L.rovaca_amd_sw_run_through_handle(ref, len(ref), seq, len(seq), asm, C.byref(sc), C.byref(mi), C.byref(mj),
+                                                    C.byref(off), cig, len(cig), C.byref(cnt))
+            results[k] = (rc, sc.value, mi.value, mj.value, off.value, cig[:cnt.value].copy())
+
+    th = [threading.Thread(target=work, args=(4 * i, 4 * i + 4)) for i in range(16)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for (ref, seq, asm), (rc, sc, mi, mj, off, cig) in zip(jobs, results):
+        o = oracle.sw_align(ref, seq, oracle.SW_PARAMS_ASSEMBLE if asm else oracle.SW_PARAMS_GENOTYPE)
+        assert rc == 0 and (sc, mi, mj, off) == (o["score"], o["max_i"], o["max_j"], o["alignment_offset"])
+        assert np.array_equal(cig, o["cigar"])
