@@ -196,8 +196,8 @@ def test_concurrent_callers_are_batched_and_each_gets_its_own_result():
     jobs = []
     for t in range(64):
         ref = acgt[rng.integers(0, 4, int(rng.integers(100, 500)))]
-        n2 = int(rng.integers(20, 150))
-        a = int(rng.integers(0, len(ref) - n2))
+        n2 = int(rng.integers(20, 100))
+        a = int(rng.integers(0, len(ref) - n2 + 1))
         seq = np.ascontiguousarray(ref[a:a + n2].copy())
         seq[rng.random(n2) < 0.05] = ord("C")
         jobs.append((np.ascontiguousarray(ref), seq, t % 2))
