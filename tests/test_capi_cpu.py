@@ -87,3 +87,19 @@ def test_sw_handle_mirror_has_the_reference_layout():
     a, b = (ctypes.c_int32 * 32)(), (ctypes.c_int32 * 32)()
     na, nb = L.rovaca_amd_sw_layout(a, 32), ref.ref_sw_layout(b, 32)
     assert na == nb == 16 and list(a[:na]) == list(b[:nb])
+
+
+def test_sw_adapter_compiles_against_the_reference_header():
+    # the in-tree build (-DROVACA_AMD_IN_ROVACA_TREE) uses the reference's own smithwaterman_common.h instead of the mirror
+    import shutil
+    import subprocess
+    import tempfile
+    inc = "/root/reference/src/haplotypecaller/common/base/include"
+    if not os.path.exists(os.path.join(inc, "smithwaterman_common.h")) or shutil.which("g++") is None:
+        pytest.skip("reference tree not available")
+    with tempfile.TemporaryDirectory() as d:
+        cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-Wall", "-Wextra", "-Werror", "-DROVACA_AMD_IN_ROVACA_TREE", "-I" + inc,
+               "-I/root/reference/third_lib/htslib/include", "-c", os.path.join(ROOT, "rovaca_amd", "host", "sw_gpu_engine.cpp"),
+               "-o", os.path.join(d, "sw_intree.o")]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
