@@ -136,7 +136,7 @@ struct Bin
     uint32_t first, count;  // range of `order`
     uint32_t lds_words_per_group;
     uint32_t max_hap_len, max_read_len;
-    int queue;              // rescue queue the launch feeds: 0 for the single-pass bins, 1..4 for the striped size ranges
+    int queue;              // rescue queue the launch feeds (phmm::kRescueQueues)
 };
 
 // Striped pairs are launched in up to four size ranges (48+ stripes of 128 rows, 24..47, 8..23, 1..7), each with the team
@@ -181,6 +181,7 @@ static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t m
 // single-pass kernels keep 16 pairs' haplotype planes in LDS per workgroup; longer haplotypes take the striped kernel
 constexpr uint32_t kSinglePassMaxHap = 4096;
 constexpr uint32_t kMaxLen = 1u << 20;
+constexpr uint64_t kQueuePerClassMinPairs = 50000;  // batches above this re-run each single-pass class from its own queue
 constexpr uint32_t kWideMaxPairs = 1536;       // single-pass launches up to this many pairs run one pair per wave
 constexpr uint32_t kRescueMaxTeams = 4096;    // workgroups of the fp64 re-run (they stride over the rescue queue)
 constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
@@ -449,6 +450,12 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     // above 256 bases or a haplotype above the single-pass LDS budget go to the striped kernel, most stripes first (longest-job-first fills the chip best).
     // Done as a counting sort over (class, length): a comparison sort was the largest host cost of a region-sized call.
     constexpr uint32_t kClasses = 17 + 64;  // 1..16, then 17 + 63 - min(stripes, 63)
+    // Rescue queue of a bin.  A large batch gives every single-pass class its own queue: the fp64 re-run of a queue is one
+    // launch whose waves hold four pairs each, and pairs of one class (read lengths within 16, haplotypes arriving longest
+    // first) keep those four in step -- mixed lengths in one queue cost the re-run a quarter of its rate.  A small batch
+    // keeps one queue: a launch per class would add more latency than the divergence costs.
+    const bool queue_per_class = n_pairs > kQueuePerClassMinPairs || getenv("PHMM_FORCE_QUEUE_PER_CLASS") != nullptr;
+    auto queue_of = [&](int id) { return id >= 17 ? id - 16 : queue_per_class ? 4 + id : 0; };
     auto class_of = [](uint32_t R, uint32_t H) -> uint32_t {
         const uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
         if (K > (uint32_t)phmm::kMaxRowsPerLane || H > kSinglePassMaxHap) {
@@ -521,7 +528,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
                         }
                 const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
                 const int id = bin_id_of_class(k);
-                rb->bins.push_back(Bin{id < 17 ? id : 0, first, end - first, plane_words, hmax, rmax, id < 17 ? 0 : id - 16});
+                rb->bins.push_back(Bin{id < 17 ? id : 0, first, end - first, plane_words, hmax, rmax, queue_of(id)});
             }
             k = k_end;
         }
@@ -560,7 +567,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
                 ++j;
             }
             const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
-            rb->bins.push_back(Bin{id < 17 ? id : 0, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax, id < 17 ? 0 : id - 16});
+            rb->bins.push_back(Bin{id < 17 ? id : 0, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax, queue_of(id)});
             i = j;
         }
     }

@@ -70,7 +70,9 @@ inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t car
 }
 // batch set-up (one launch): optional device-side read preparation, haplotype bit planes, rescue queue reset
 constexpr int kSetupThreads = 128;
-constexpr int kRescueQueues = 5;  // rescue queues per batch: the single-pass bins share one, each striped size range has one
+// rescue queues per batch: 0 = all single-pass bins of a small batch, 1..4 = the striped size ranges, 5..20 = one per
+// single-pass rows-per-lane class of a large batch (pairs of one class re-run together: equal stripes, sorted haplotypes)
+constexpr int kRescueQueues = 24;
 struct SetupArgs
 {
     // haplotype planes

@@ -119,6 +119,14 @@ def test_rescue_path_fp64(engine, rows, monkeypatch):
     assert (raw < np.float32(1e-28)).sum() > 10
 
 
+def test_rescue_queue_per_length_class(engine, monkeypatch):
+    # large batches re-run every single-pass length class from its own queue; forced here on a small mixed-length batch
+    monkeypatch.setenv("PHMM_FORCE_QUEUE_PER_CLASS", "1")
+    b = synth.make_batch(seed=64, n_regions=6, reads=20, haps=6, read_len=(20, 250), hap_len=(260, 500), sub_rate=0.15, qual=30)
+    raw, l10 = _check_against_oracle(engine, b)
+    assert (raw < np.float32(1e-28)).sum() > 50
+
+
 def test_cross_product_mode_and_N_symbols(engine):
     b = synth.make_batch(seed=63, n_regions=1, reads=23, haps=7, read_len=(30, 120), hap_len=200, n_rate=0.02,
                          hap_n_rate=0.01)
