@@ -197,8 +197,8 @@ struct phmm_resident
     DevBuf<uint8_t> blob;
     DevView<uint8_t> read_bases, read_qual, hap_bases, read_mapq;
     DevView<uint32_t> read_off, read_len, hap_off, hap_len, pair_read, pair_hap, order, plane_off, word_owner;
-    DevBuf<uint8_t> read_ins, read_del, read_gcp;  // uploaded (prepared batches) or written by prep_reads_kernel
-    bool del_aliases_ins = false;  // device-prepared batches: the deletion gap-open IS the insertion array (pairhmm_internal.cpp:425)
+    DevView<uint8_t> read_ins, read_del, read_gcp;  // prepared batches: inside `blob`; otherwise the two buffers below
+    DevBuf<uint8_t> prep_gop, prep_gcp;             // written by the set-up launch (device-side read preparation)
     DevBuf<uint32_t> planes;
     DevBuf<float> raw32;
     DevBuf<double> raw64;
@@ -408,6 +408,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     };
     const size_t o_bases = reserve(read_bytes), o_qual = reserve(read_bytes);
     const size_t o_mapq = reserve(prep ? b->n_reads : 0);
+    const size_t o_ins = reserve(prep ? 0 : read_bytes), o_del = reserve(prep ? 0 : read_bytes), o_gcp = reserve(prep ? 0 : read_bytes);
     const size_t o_roff = reserve(b->n_reads * sizeof(uint32_t)), o_rlen = reserve(b->n_reads * sizeof(uint32_t));
     const size_t o_hap = reserve(hap_bytes);
     const size_t o_hoff = reserve(b->n_haps * sizeof(uint32_t)), o_hlen = reserve(b->n_haps * sizeof(uint32_t));
@@ -422,6 +423,11 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
         memcpy(stage + o_qual, b->read_qual, read_bytes);
     }
     if (prep && b->n_reads) memcpy(stage + o_mapq, prep->read_mapq, b->n_reads);
+    if (!prep && read_bytes) {
+        memcpy(stage + o_ins, b->read_ins, read_bytes);
+        memcpy(stage + o_del, b->read_del, read_bytes);
+        memcpy(stage + o_gcp, b->read_gcp, read_bytes);
+    }
     if (b->n_reads) {
         memcpy(stage + o_roff, b->read_off, b->n_reads * sizeof(uint32_t));
         memcpy(stage + o_rlen, b->read_len, b->n_reads * sizeof(uint32_t));
@@ -590,15 +596,17 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     rb->order = {reinterpret_cast<uint32_t *>(base + o_order), (size_t)n_pairs};
     rb->plane_off = {reinterpret_cast<uint32_t *>(base + o_poff), b->n_haps};
     rb->word_owner = {reinterpret_cast<uint32_t *>(base + o_owner), (size_t)slots};
-    rb->del_aliases_ins = prep != nullptr;
     if (prep) {
-        HIP_TRY(rb->read_ins.alloc(read_bytes));
-        HIP_TRY(rb->read_gcp.alloc(read_bytes));
+        HIP_TRY(rb->prep_gop.alloc(read_bytes));
+        HIP_TRY(rb->prep_gcp.alloc(read_bytes));
+        rb->read_ins = {rb->prep_gop.p, (size_t)read_bytes};
+        rb->read_del = rb->read_ins;  // pairhmm_internal.cpp:425
+        rb->read_gcp = {rb->prep_gcp.p, (size_t)read_bytes};
     }
     else {
-        HIP_TRY(rb->read_ins.upload(b->read_ins, read_bytes, st));
-        HIP_TRY(rb->read_del.upload(b->read_del, read_bytes, st));
-        HIP_TRY(rb->read_gcp.upload(b->read_gcp, read_bytes, st));
+        rb->read_ins = {base + o_ins, (size_t)read_bytes};
+        rb->read_del = {base + o_del, (size_t)read_bytes};
+        rb->read_gcp = {base + o_gcp, (size_t)read_bytes};
     }
     HIP_TRY(rb->planes.alloc(slots * phmm::kPlanes));
     // the rescue count lives behind the fp32 sums so that both come back in one copy
@@ -633,7 +641,6 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
         HIP_TRY(phmm::launch_setup(sa, st));
         rb->queue_is_empty = true;
     }
-    if (!prep) HIP_TRY(hipStreamSynchronize(st));  // read_ins / read_del / read_gcp were copied straight from caller memory
     PHASE(3);
     return PHMM_OK;
 }
@@ -691,7 +698,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.read_bases = rb->read_bases.p;
         a.read_qual = rb->read_qual.p;
         a.read_ins = rb->read_ins.p;
-        a.read_del = rb->del_aliases_ins ? rb->read_ins.p : rb->read_del.p;
+        a.read_del = rb->read_del.p;
         a.read_gcp = rb->read_gcp.p;
         a.read_off = rb->read_off.p;
         a.read_len = rb->read_len.p;
@@ -808,7 +815,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
         a.read_bases = rb->read_bases.p;
         a.read_qual = rb->read_qual.p;
         a.read_ins = rb->read_ins.p;
-        a.read_del = rb->del_aliases_ins ? rb->read_ins.p : rb->read_del.p;
+        a.read_del = rb->read_del.p;
         a.read_gcp = rb->read_gcp.p;
         a.read_off = rb->read_off.p;
         a.read_len = rb->read_len.p;
@@ -936,7 +943,7 @@ int phmm_download_read_table(phmm_context *c, phmm_resident *rb, uint8_t *qual, 
     if (!c || !rb) return fail(PHMM_E_INVALID, "phmm_download_read_table: null argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = rb->read_qual.n;
-    const uint8_t *dp = rb->del_aliases_ins ? rb->read_ins.p : rb->read_del.p;
+    const uint8_t *dp = rb->read_del.p;
     if (qual && n) HIP_TRY(hipMemcpyAsync(qual, rb->read_qual.p, n, hipMemcpyDeviceToHost, c->stream));
     if (ins && n) HIP_TRY(hipMemcpyAsync(ins, rb->read_ins.p, n, hipMemcpyDeviceToHost, c->stream));
     if (del && n) HIP_TRY(hipMemcpyAsync(del, dp, n, hipMemcpyDeviceToHost, c->stream));
