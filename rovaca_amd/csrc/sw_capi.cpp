@@ -88,7 +88,7 @@ struct swhip_context
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBytes blob, bt, scratch, out, cigars;
-    HostBytes stage, back;
+    HostBytes stage, back, back_cigars;
 };
 
 extern "C" {
@@ -308,7 +308,7 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     // ---- download: results + the element count, then the elements ----
     const size_t res_bytes = n * sizeof(swhip::Alignment);
     const size_t b_cur = (res_bytes + 255) & ~size_t(255);
-    HIP_TRY(c->back.ensure(b_cur + 256 + worst_elems * 4));
+    HIP_TRY(c->back.ensure(b_cur + 256));
     uint8_t *bp = static_cast<uint8_t *>(c->back.p);
     HIP_TRY(hipMemcpyAsync(bp, c->out.p, res_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(bp + b_cur, a.cigar_cursor, 4, hipMemcpyDeviceToHost, st));
@@ -329,9 +329,11 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     if (used > cigar_capacity) return fail(SWHIP_E_CAPACITY, "swhip_align: %u CIGAR elements, room for %llu", used, (unsigned long long)cigar_capacity);
     if (used) {
         if (!cigars) return fail(SWHIP_E_INVALID, "swhip_align: null cigars buffer");
-        HIP_TRY(hipMemcpyAsync(bp + b_cur + 256, c->cigars.p, (size_t)used * 4, hipMemcpyDeviceToHost, st));
+        // pinned staging sized for what was produced (the worst case is sum(len1 + len2 + 2) elements)
+        HIP_TRY(c->back_cigars.ensure((size_t)used * 4));
+        HIP_TRY(hipMemcpyAsync(c->back_cigars.p, c->cigars.p, (size_t)used * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        memcpy(cigars, bp + b_cur + 256, (size_t)used * 4);
+        memcpy(cigars, c->back_cigars.p, (size_t)used * 4);
     }
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SWHIP_OK;
