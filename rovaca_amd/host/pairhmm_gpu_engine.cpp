@@ -14,6 +14,8 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+
+#include <pthread.h>
 #include <vector>
 
 #include "../../include/pairhmm_hip.h"
@@ -146,6 +148,8 @@ public:
 private:
     void run()
     {
+        // named like the reference's own threads (haplotypecaller_engine.cpp:120) so that perf / top -H attribute the time
+        pthread_setname_np(pthread_self(), "phmm-gpu-disp");
         phmm_context *ctx = nullptr;
         if (phmm_create(device_, nullptr, &ctx) != PHMM_OK) {
             fprintf(stderr, "[rovaca_amd] pairhmm: cannot create a device context: %s\n", phmm_last_error());

@@ -11,6 +11,8 @@
 #include <mutex>
 #include <thread>
 
+#include <pthread.h>
+
 #include "../../include/smithwaterman_hip.h"
 
 namespace
@@ -127,6 +129,8 @@ private:
     }
     void run()
     {
+        // named like the reference's own threads (haplotypecaller_engine.cpp:120) so that perf / top -H attribute the time
+        pthread_setname_np(pthread_self(), "sw-gpu-disp");
         std::vector<Request *> taken, group;
         std::vector<SwJob> jobs;
         std::vector<SwAlignment> out;
