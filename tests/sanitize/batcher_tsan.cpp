@@ -1,0 +1,152 @@
+// batcher_tsan.cpp -- ThreadSanitizer run of the two cross-region batchers (pairhmm_gpu_engine.cpp, sw_gpu_engine.cpp) WITHOUT a
+// GPU: the C ABIs they call are replaced, in this test binary only, by deterministic stand-ins (a value that depends on the
+// read and haplotype bytes alone), so that every worker can check that it got its own region's numbers however the dispatchers
+// merged the submissions, while TSan watches the hand-offs.  Test infrastructure: the product libraries are not involved and
+// still have no CPU path.  Built and run by tests/test_sanitizers.py.
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory_resource>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../include/pairhmm_hip.h"
+#include "../../include/smithwaterman_hip.h"
+#include "../../rovaca_amd/host/pairhmm_gpu_engine.h"
+#include "../../rovaca_amd/host/sw_gpu_engine.h"
+
+// ---------------- stand-in device libraries ----------------
+struct phmm_context
+{
+    int dummy;
+};
+struct swhip_context
+{
+    int dummy;
+};
+static uint32_t hash_bytes(const uint8_t *p, uint32_t n)
+{
+    uint32_t h = 2166136261u;
+    for (uint32_t i = 0; i < n; ++i) h = (h ^ p[i]) * 16777619u;
+    return h;
+}
+static double fake_likelihood(const uint8_t *read, uint32_t R, const uint8_t *hap, uint32_t H)
+{
+    return -1.0 - (double)(hash_bytes(read, R) % 997u) / 100.0 - (double)(hash_bytes(hap, H) % 101u) / 50.0;
+}
+extern "C" {
+int phmm_abi_version(void) { return PHMM_ABI_VERSION; }
+int phmm_device_count(void) { return 1; }
+const char *phmm_last_error(void) { return ""; }
+int phmm_create(int, void *, phmm_context **out)
+{
+    *out = new phmm_context{0};
+    return PHMM_OK;
+}
+void phmm_destroy(phmm_context *c) { delete c; }
+int phmm_compute(phmm_context *, const phmm_batch *b, float *, double *out_log10, phmm_stats *)
+{
+    std::this_thread::sleep_for(std::chrono::microseconds(150));  // a device round trip: lets submissions pile up
+    for (uint64_t p = 0; p < b->n_pairs; ++p) {
+        const uint32_t r = b->pair_read[p], h = b->pair_hap[p];
+        out_log10[p] = fake_likelihood(b->read_bases + b->read_off[r], b->read_len[r], b->hap_bases + b->hap_off[h], b->hap_len[h]);
+    }
+    return PHMM_OK;
+}
+int swhip_abi_version(void) { return SWHIP_ABI_VERSION; }
+const char *swhip_last_error(void) { return ""; }
+int swhip_create(int, void *, swhip_context **out)
+{
+    *out = new swhip_context{0};
+    return SWHIP_OK;
+}
+void swhip_destroy(swhip_context *c) { delete c; }
+int swhip_align(swhip_context *, const swhip_params *, const swhip_batch *b, swhip_alignment *out, uint32_t *cigars, uint64_t cap,
+                uint64_t *used, swhip_stats *)
+{
+    std::this_thread::sleep_for(std::chrono::microseconds(150));
+    uint64_t at = 0;
+    for (uint64_t p = 0; p < b->n_pairs; ++p) {
+        const uint32_t r = b->pair_ref[p], s = b->pair_seq[p];
+        out[p] = swhip_alignment{};
+        out[p].score = (int32_t)(hash_bytes(b->seq_bases + b->seq_off[s], b->seq_len[s]) % 100000u);
+        out[p].alignment_offset = (int16_t)(hash_bytes(b->ref_bases + b->ref_off[r], b->ref_len[r]) % 300u);
+        out[p].cigar_off = (uint32_t)at;
+        out[p].cigar_count = 1;
+        if (at < cap) cigars[at] = (b->seq_len[s] << 4) | 0u;
+        ++at;
+    }
+    *used = at;
+    return at > cap ? SWHIP_E_CAPACITY : SWHIP_OK;
+}
+}
+
+using namespace rovaca;
+
+int main()
+{
+    if (!init_pairhmm_ptr_gpu(0)) return 2;
+    const int threads = 12, per_thread = 40;
+    std::atomic<int> bad{0};
+    auto work = [&](int t) {
+        std::mt19937 rng(100 + t);
+        const char acgt[] = "ACGT";
+        for (int k = 0; k < per_thread; ++k) {
+            const int n_reads = 1 + rng() % 12, n_haps = 1 + rng() % 5;
+            std::vector<ReadRecord> reads;
+            std::vector<Haplotype> haps;
+            std::vector<std::vector<uint8_t>> rb(n_reads), hb(n_haps);
+            for (auto &h : hb) {
+                h.resize(60 + rng() % 100);
+                for (auto &c : h) c = acgt[rng() & 3];
+                haps.emplace_back(h.data(), (uint32_t)h.size());
+            }
+            for (auto &r : rb) {
+                r.resize(20 + rng() % 60);
+                for (auto &c : r) c = acgt[rng() & 3];
+                std::vector<uint8_t> q(r.size(), 30);
+                reads.emplace_back(r.data(), q.data(), (uint32_t)r.size(), (uint8_t)60);
+            }
+            std::pmr::monotonic_buffer_resource arena;
+            ReadVector rs{&arena};
+            HaplotypeVector hs{&arena};
+            for (auto &r : reads) rs.push_back(&r);
+            for (auto &h : haps) hs.push_back(&h);
+            DoubleVector2D lik = call_pairhmm(hs, rs, 18, PcrIndelModel::NONE, &arena);
+            // every surviving read's row must be this region's own numbers (normalisation only caps from below)
+            for (size_t r = 0; r < rs.size(); ++r) {
+                const size_t orig = (size_t)(rs[r] - reads.data());
+                double best = -1e300;
+                for (int h = 0; h < n_haps; ++h) best = std::max(best, fake_likelihood(rb[orig].data(), (uint32_t)rb[orig].size(), hb[h].data(), (uint32_t)hb[h].size()));
+                for (int h = 0; h < n_haps; ++h) {
+                    const double want = std::max(fake_likelihood(rb[orig].data(), (uint32_t)rb[orig].size(), hb[h].data(), (uint32_t)hb[h].size()), best - 4.5);
+                    if (lik[h][r] != want) ++bad;
+                }
+            }
+            // Smith-Waterman batcher: one request per region
+            std::vector<SwJob> jobs;
+            for (int r = 0; r < n_reads; ++r) jobs.push_back(SwJob{hb[r % n_haps].data(), (int32_t)hb[r % n_haps].size(), rb[r].data(), (int32_t)rb[r].size()});
+            std::vector<SwAlignment> aln;
+            const sw_parameters para{10, -15, -30, -5};
+            if (!sw_hip_align_batch(jobs.data(), jobs.size(), para, aln)) ++bad;
+            for (int r = 0; r < n_reads; ++r) {
+                if (aln[r].score != (int32_t)(hash_bytes(rb[r].data(), (uint32_t)rb[r].size()) % 100000u)) ++bad;
+                if (aln[r].cigar.size() != 1 || aln[r].cigar[0] != (((uint32_t)rb[r].size() << 4) | 0u)) ++bad;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+    uint64_t regions = 0, subs = 0, rq = 0, sw_subs = 0;
+    gpu_pairhmm_batching_stats(&regions, &subs);
+    sw_hip_batching_stats(&rq, &sw_subs);
+    printf("batchers: %llu regions in %llu submissions, %llu alignment requests in %llu submissions, %d mismatches\n",
+           (unsigned long long)regions, (unsigned long long)subs, (unsigned long long)rq, (unsigned long long)sw_subs, bad.load());
+    if (bad.load() || regions != (uint64_t)threads * per_thread || subs >= regions || sw_subs >= rq) return 1;
+    fflush(stdout);
+    _Exit(0);  // the dispatcher threads are never joined (by design); leave without static teardown
+}
