@@ -710,6 +710,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.order = rb->order.p + bin.first;
         a.n_pairs = bin.count;
         a.lds_words_per_group = bin.lds_words_per_group;
+        a.no_early_exit = getenv("PHMM_NO_EARLY_EXIT") ? 1u : 0u;  // tests
         a.ph2pr = c->ph2pr_f32.p;
         a.mm_table = c->mm_f32.p;
         a.out_raw = rb->raw32.p;
@@ -828,6 +829,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
         a.n_pairs = 0;
         a.n_pairs_dev = rb->rescue_count.p + qi;
         a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(p.max_hap);
+        a.no_early_exit = getenv("PHMM_NO_EARLY_EXIT") ? 1u : 0u;  // tests
         a.ph2pr = c->ph2pr_f64.p;
         a.mm_table = c->mm_f64.p;
         a.out_raw = rb->raw64.p;

@@ -39,6 +39,7 @@ struct KernelArgs
     const uint32_t *order;
     uint32_t n_pairs;
     uint32_t lds_words_per_group;
+    uint32_t no_early_exit;  // test hook: 1 = sweep every superstep even where everything is zero
     // lookup tables (core/context.h) in the arithmetic type of the launch
     const void *ph2pr;
     const void *mm_table;

@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
         uint32_t cls_lo = 0, cls_hi = 0;
         T aM = 0, aX = 0, aY = 0, bM = 0, bX = 0, bY = 0;
         T preM[2], preX[2], preY[2];
+        bool park_nz[2] = {true, true};  // does the parked carry block (ring half) hold anything but zeros
         T curM = 0, curX = 0, curY = 0;  // the row above lane 0 at the next step's column (prefetched from the ring)
         T sumM = 0, sumX = 0;
         uint32_t Tg = 0;
@@ -517,12 +518,15 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
         };
         auto carry_park = [&](uint32_t blk) {
             const uint32_t base = (blk & 1u) * 32u + (lane & 15u);
+            bool nz = false;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 ring[base + 16 * q] = preM[q];
                 ring[kRing + base + 16 * q] = preX[q];
                 ring[2 * kRing + base + 16 * q] = preY[q];
+                nz = nz || preM[q] != 0 || preX[q] != 0 || preY[q] != 0;
             }
+            park_nz[blk & 1u] = nz;  // this lane's share of the block; the groups' lanes are combined when the block is consumed
         };
         T nxtM = 0, nxtX = 0, nxtY = 0;
         auto ring_fetch = [&](uint32_t t) {  // column t -> the "next" registers (issued a whole step before they are used)
@@ -704,7 +708,29 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                         Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
                     }
                     Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
-                    if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
+                    // A superstep with nothing but zeros going in -- the carry block it consumes and every value the wave
+                    // holds -- puts nothing but zeros out (each value is a sum of non-negative products of its neighbours,
+                    // and fp32 runs flush-to-zero): write the zero carry columns and move on.  This is where long reads
+                    // spend most of their fp32 pass: a 10-kbp read underflows for good after some 2 000 rows.
+                    bool lane_nz = park_nz[c & 1u] || aM != 0 || aX != 0 || aY != 0 || bM != 0 || bX != 0 || bY != 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) lane_nz = lane_nz || M[k] != 0 || X[k] != 0 || Y[k] != 0;
+                    if (__ballot(lane_nz && Tg != 0) == 0 && !a.no_early_exit) {
+                        if (Tg != 0 && v + 1 != max_stripes) {
+                            struct V3
+                            {
+                                T m, x, y;
+                            };
+                            for (uint32_t t = t0 + lane; t <= t1 && t <= Tg; t += G) {
+                                if (t > (uint32_t)(G - 1)) *reinterpret_cast<V3 *>(wbase + ((t - (G - 1)) * kGroups + grp) * 3u) = V3{0, 0, 0};
+                            }
+                        }
+                        ring_fetch(t1 + 1);
+                        curM = nxtM;
+                        curX = nxtX;
+                        curY = nxtY;
+                    }
+                    else if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
                         // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
                         if (v + 1 == max_stripes)
                             superstep_full(t0, std::true_type{});

@@ -292,6 +292,17 @@ def test_team_kernel_every_width(engine, waves, lanes, monkeypatch):
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
+@pytest.mark.parametrize("skip_zero_supersteps", [True, False])
+def test_long_noisy_reads_with_and_without_the_zero_superstep_shortcut(engine, skip_zero_supersteps, monkeypatch):
+    # long reads spend most of their sweep on cells that are exactly zero; the team kernel skips supersteps whose inputs and
+    # state are all zero.  Same bits either way, and the same as the oracle.
+    if not skip_zero_supersteps:
+        monkeypatch.setenv("PHMM_NO_EARLY_EXIT", "1")
+    b = synth.make_batch(seed=91, n_regions=2, reads=4, haps=3, read_len=(1500, 4000), hap_len=(1800, 4500), sub_rate=0.02)
+    raw, l10 = _check_against_oracle(engine, b)
+    assert (raw == 0).all()  # fp32 underflows for good on reads this long; the fp64 re-run decides
+
+
 def test_team_pipeline_with_a_haplotype_shorter_than_the_pipeline(engine):
     # found by tests/debug/fuzz_gpu.py: the team shape (waves per pair) is chosen for the longest haplotype of the launch; a
     # pair of the same launch whose haplotype is shorter than lag * waves * 32 columns must still see its carry written
