@@ -390,9 +390,12 @@ template <int G> constexpr uint32_t team_lag() { return G == 64 ? 6u : 4u; }
 // so few pairs that four-per-wave would leave the chip empty: one long-read pair then keeps up to WP waves busy)
 template <typename T, int K, bool UG, int WP, int G>
 #ifndef PHMM_TEAM_WAVES_F32
-#define PHMM_TEAM_WAVES_F32 2
+#define PHMM_TEAM_WAVES_F32 4
 #endif
-__global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 : 2) pairhmm_team_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
+#ifndef PHMM_TEAM_WAVES_F64
+#define PHMM_TEAM_WAVES_F64 2
+#endif
+__global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 : PHMM_TEAM_WAVES_F64) pairhmm_team_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
 {
     extern __shared__ uint32_t lds[];
     constexpr int S = G * K;
