@@ -703,7 +703,6 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                         carry_load(c + 2);
                     }
                     const uint32_t t0 = 32u * c + 1u;
-                    masks_reload(t0);
                     const uint32_t t1 = min(t0 + 31u, Tmax);
                     uint32_t Tmin = Tg;  // wave-uniform: the last step at which every group of the wave is still sweeping
                     if (kGroups > 1) {
@@ -733,25 +732,28 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                         curX = nxtX;
                         curY = nxtY;
                     }
-                    else if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
-                        // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
-                        if (v + 1 == max_stripes)
-                            superstep_full(t0, std::true_type{});
-                        else
-                            superstep_full(t0, std::false_type{});
-                    }
                     else {
-                        for (uint32_t t = t0; t <= t1; ++t) {
-                            ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
-                            if ((t > lane) && (t <= Tg)) {
-                                if (t & 1u)
-                                    step(t, aM, aX, aY, bM, bX, bY, last);
-                                else
-                                    step(t, bM, bX, bY, aM, aX, aY, last);
+                        masks_reload(t0);
+                        if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
+                            // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
+                            if (v + 1 == max_stripes)
+                                superstep_full(t0, std::true_type{});
+                            else
+                                superstep_full(t0, std::false_type{});
+                        }
+                        else {
+                            for (uint32_t t = t0; t <= t1; ++t) {
+                                ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
+                                if ((t > lane) && (t <= Tg)) {
+                                    if (t & 1u)
+                                        step(t, aM, aX, aY, bM, bX, bY, last);
+                                    else
+                                        step(t, bM, bX, bY, aM, aX, aY, last);
+                                }
+                                curM = nxtM;
+                                curX = nxtX;
+                                curY = nxtY;
                             }
-                            curM = nxtM;
-                            curX = nxtX;
-                            curY = nxtY;
                         }
                     }
                     if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == G - 1) {
