@@ -167,7 +167,9 @@ static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t m
     const uint32_t stripes = (max_read + sh.lanes * rows_per_lane - 1) / (sh.lanes * rows_per_lane);
     const uint32_t supersteps = (max_hap + (uint32_t)sh.lanes - 1 + 31) / 32;
     const uint32_t lag = sh.lanes == 64 ? 6u : 4u;  // team_lag<G>() of the kernel
-    if (batches < 2048 && stripes >= (sh.lanes == 64 ? 16u : 8u) && supersteps >= lag * 8 + 12)
+    // (one pair per wave: since all-zero supersteps are skipped only one or two waves of a team have work at any time, and
+    // eight waves per pair measured slower than four on config 5)
+    if (sh.lanes == 16 && batches < 2048 && stripes >= 8 && supersteps >= lag * 8 + 12)
         sh.waves = 8;
     else if (batches < 4096 && stripes >= 4 && supersteps >= lag * 4 + 12)
         sh.waves = 4;
