@@ -1,5 +1,5 @@
 """Randomised parity fuzz on the GPU (not collected by pytest): random batches of random shapes through both C ABIs against the
-CPU restatements.  usage: python tests/debug/fuzz_gpu.py [seconds] [seed]"""
+CPU restatements.  usage: python tests/debug/fuzz_gpu.py [seconds] [seed] [long]"""
 import os
 import sys
 import time
@@ -21,10 +21,11 @@ n_ph = n_sw = it = 0
 while time.time() < t_end:
     it += 1
     # ---- PairHMM ----
-    mode = int(rng.integers(0, 4))
-    rmax = [40, 260, 700, 2600][mode]
-    hmax = [80, 520, 1500, 5000][mode]
-    n_reads, n_haps = int(rng.integers(1, [40, 30, 10, 4][mode])), int(rng.integers(1, [12, 10, 5, 3][mode]))
+    long_bias = len(sys.argv) > 3 and sys.argv[3] == "long"  # mostly long reads: team kernels, zero-superstep shortcut
+    mode = int(rng.choice([2, 3, 3, 4])) if long_bias else int(rng.integers(0, 4))
+    rmax = [40, 260, 700, 2600, 7000][mode]
+    hmax = [80, 520, 1500, 5000, 9000][mode]
+    n_reads, n_haps = int(rng.integers(1, [40, 30, 10, 4, 3][mode])), int(rng.integers(1, [12, 10, 5, 3, 3][mode]))
     haps = [acgt[rng.integers(0, 5 if rng.random() < 0.2 else 4, int(rng.integers(1, hmax)))] for _ in range(n_haps)]
     reads = []
     general = rng.random() < 0.3
