@@ -20,7 +20,12 @@
 //     one `v_cndmask_b32` per cell;
 //   * rows are right-aligned in the 16*K slots, so the last read row is always slot K-1 of lane 15 and the
 //     final sum is accumulated there in the reference's order.  Padding rows above the read reproduce the
-//     boundary row (M = X = 0, Y = 2^120/H) exactly.
+//     boundary row (M = X = 0, Y = 2^120/H) exactly;
+//   * the same kernel exists with G = 64 lanes per pair (one pair per wave, `wave_shr:1`) for launches of a region or
+//     two, where four pairs per wave would leave most SIMDs empty;
+//   * reads above 256 rows, haplotypes above 4096 columns and every fp64 re-run take the striped "team" kernel further
+//     down: stripes of G*K rows chained through a carry row, several waves per pair as a software pipeline, and
+//     supersteps whose inputs and state are all zero are skipped (far from the alignment band everything is).
 //
 // No MFMA: this is a first-order recurrence, not a contraction.  No CUDA-isms: wave64, DPP, LDS.
 #include <hip/hip_runtime.h>
