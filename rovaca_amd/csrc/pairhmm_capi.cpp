@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/pairhmm_hip.h"
@@ -218,6 +220,24 @@ struct phmm_resident
     double last_kernel_ms = 0.0;
 };
 
+// Host loops over the pairs of a BIG batch (binning, the final log10) are split over a few threads; a region-sized call
+// never gets here.
+constexpr uint64_t kParallelMinPairs = 1u << 18;
+template <typename F>
+static void parallel_ranges(uint64_t n, unsigned n_threads, F &&fn)  // fn(lo, hi, thread index)
+{
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
+    fn(0, n / n_threads, 0u);
+    for (auto &x : th) x.join();
+}
+static unsigned host_threads()
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(8u, hw ? hw : 1u));
+}
+
+
 extern "C" {
 
 int phmm_abi_version(void) { return PHMM_ABI_VERSION; }
@@ -424,24 +444,33 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     HIP_TRY(rb->stage.ensure(total));
     HIP_TRY(rb->blob.alloc(total));
     uint8_t *stage = static_cast<uint8_t *>(rb->stage.p);
+    auto copy = [](void *dst, const void *src, size_t bytes) {  // big tables of a big batch: a few threads share the copy
+        if (bytes < (size_t(4) << 20)) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        parallel_ranges(bytes, std::min(4u, host_threads()), [&](uint64_t lo, uint64_t hi, unsigned) {
+            memcpy(static_cast<uint8_t *>(dst) + lo, static_cast<const uint8_t *>(src) + lo, hi - lo);
+        });
+    };
     if (read_bytes) {
-        memcpy(stage + o_bases, b->read_bases, read_bytes);
-        memcpy(stage + o_qual, b->read_qual, read_bytes);
+        copy(stage + o_bases, b->read_bases, read_bytes);
+        copy(stage + o_qual, b->read_qual, read_bytes);
     }
-    if (prep && b->n_reads) memcpy(stage + o_mapq, prep->read_mapq, b->n_reads);
+    if (prep && b->n_reads) copy(stage + o_mapq, prep->read_mapq, b->n_reads);
     if (!prep && read_bytes) {
-        memcpy(stage + o_ins, b->read_ins, read_bytes);
-        memcpy(stage + o_del, b->read_del, read_bytes);
-        memcpy(stage + o_gcp, b->read_gcp, read_bytes);
+        copy(stage + o_ins, b->read_ins, read_bytes);
+        copy(stage + o_del, b->read_del, read_bytes);
+        copy(stage + o_gcp, b->read_gcp, read_bytes);
     }
     if (b->n_reads) {
-        memcpy(stage + o_roff, b->read_off, b->n_reads * sizeof(uint32_t));
-        memcpy(stage + o_rlen, b->read_len, b->n_reads * sizeof(uint32_t));
+        copy(stage + o_roff, b->read_off, b->n_reads * sizeof(uint32_t));
+        copy(stage + o_rlen, b->read_len, b->n_reads * sizeof(uint32_t));
     }
-    if (hap_bytes) memcpy(stage + o_hap, b->hap_bases, hap_bytes);
+    if (hap_bytes) copy(stage + o_hap, b->hap_bases, hap_bytes);
     if (b->n_haps) {
-        memcpy(stage + o_hoff, b->hap_off, b->n_haps * sizeof(uint32_t));
-        memcpy(stage + o_hlen, b->hap_len, b->n_haps * sizeof(uint32_t));
+        copy(stage + o_hoff, b->hap_off, b->n_haps * sizeof(uint32_t));
+        copy(stage + o_hlen, b->hap_len, b->n_haps * sizeof(uint32_t));
     }
     uint32_t *pr = reinterpret_cast<uint32_t *>(stage + o_pr), *ph = reinterpret_cast<uint32_t *>(stage + o_ph);
     uint32_t *order = reinterpret_cast<uint32_t *>(stage + o_order);
@@ -499,28 +528,56 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
         std::vector<uint32_t> &hist = c->bin_hist, &slot = c->bin_slot;
         hist.assign(table + 1, 0);
         slot.resize(n_pairs);
-        auto visit = [&](uint64_t p, uint32_t r, uint32_t h) {
-            const uint32_t R = b->read_len[r], H = b->hap_len[h];
-            const uint32_t k = class_of(R, H);
-            class_rmax[k] = std::max(class_rmax[k], R);
-            const uint32_t at = rank[k] * hrange + (max_hap - H);
-            pr[p] = r;
-            ph[p] = h;
-            slot[p] = at;
-            ++hist[at + 1];
-            cells += (uint64_t)R * H;
+        const unsigned T = (n_pairs >= kParallelMinPairs && table <= (1u << 16)) ? host_threads() : 1u;
+        std::vector<std::vector<uint32_t>> th_hist(T > 1 ? T : 0);
+        std::vector<uint64_t> th_cells(T, 0);
+        std::vector<uint32_t> th_rmax((size_t)T * kClasses, 0);
+        std::atomic<uint64_t> bad_pair{UINT64_MAX};
+        auto count_range = [&](uint64_t lo, uint64_t hi, unsigned t) {
+            uint32_t *h_t = T > 1 ? th_hist[t].data() : hist.data() + 1;  // one thread counts straight into hist[at + 1]
+            uint32_t *rmax_t = th_rmax.data() + (size_t)t * kClasses;
+            uint64_t cells_t = 0;
+            for (uint64_t p = lo; p < hi; ++p) {
+                uint32_t r, h;
+                if (cross) {
+                    r = (uint32_t)(p / b->n_haps);
+                    h = (uint32_t)(p % b->n_haps);
+                }
+                else {
+                    r = b->pair_read[p];
+                    h = b->pair_hap[p];
+                    if (r >= b->n_reads || h >= b->n_haps) {
+                        uint64_t expect = UINT64_MAX;
+                        bad_pair.compare_exchange_strong(expect, p);
+                        return;
+                    }
+                }
+                const uint32_t R = b->read_len[r], H = b->hap_len[h];
+                const uint32_t k = class_of(R, H);
+                rmax_t[k] = std::max(rmax_t[k], R);
+                const uint32_t at = rank[k] * hrange + (max_hap - H);
+                pr[p] = r;
+                ph[p] = h;
+                slot[p] = at;
+                ++h_t[at];
+                cells_t += (uint64_t)R * H;
+            }
+            th_cells[t] = cells_t;
         };
-        if (cross) {
-            uint64_t p = 0;
-            for (uint32_t r = 0; r < b->n_reads; ++r)
-                for (uint32_t h = 0; h < b->n_haps; ++h) visit(p++, r, h);
+        if (T > 1) {
+            for (auto &v : th_hist) v.assign(table, 0);
+            parallel_ranges(n_pairs, T, count_range);
+            for (unsigned t = 0; t < T; ++t)
+                for (uint64_t i = 0; i < table; ++i) hist[i + 1] += th_hist[t][i];
         }
         else {
-            for (uint64_t p = 0; p < n_pairs; ++p) {
-                if (b->pair_read[p] >= b->n_reads || b->pair_hap[p] >= b->n_haps)
-                    return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)p);
-                visit(p, b->pair_read[p], b->pair_hap[p]);
-            }
+            count_range(0, n_pairs, 0);
+        }
+        if (bad_pair.load() != UINT64_MAX)
+            return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)bad_pair.load());
+        for (unsigned t = 0; t < T; ++t) {
+            cells += th_cells[t];
+            for (uint32_t k = 0; k < kClasses; ++k) class_rmax[k] = std::max(class_rmax[k], th_rmax[(size_t)t * kClasses + k]);
         }
         for (uint64_t i = 0; i < table; ++i) hist[i + 1] += hist[i];  // hist[i] = first position of slot i
         // bins: classes 1..16 one each, the striped classes in four size ranges
@@ -544,7 +601,24 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
             }
             k = k_end;
         }
-        for (uint64_t p = 0; p < n_pairs; ++p) order[hist[slot[p]]++] = (uint32_t)p;
+        if (T > 1) {
+            // stable scatter: inside a slot thread 0's pairs come first, then thread 1's, ... -- the order one thread gives
+            for (uint64_t i = 0; i < table; ++i) {
+                uint32_t run = hist[i];
+                for (unsigned t = 0; t < T; ++t) {
+                    const uint32_t cnt = th_hist[t][i];
+                    th_hist[t][i] = run;
+                    run += cnt;
+                }
+            }
+            parallel_ranges(n_pairs, T, [&](uint64_t lo, uint64_t hi, unsigned t) {
+                uint32_t *start = th_hist[t].data();
+                for (uint64_t p = lo; p < hi; ++p) order[start[slot[p]]++] = (uint32_t)p;
+            });
+        }
+        else {
+            for (uint64_t p = 0; p < n_pairs; ++p) order[hist[slot[p]]++] = (uint32_t)p;
+        }
     }
     else {
         // sparse length distribution: comparison sort on (class, length, index)
@@ -926,13 +1000,19 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
         if (out_raw_f32) memcpy(out_raw_f32, rp, n * sizeof(float));
         if (out_log10) {
             // pairhmm_internal.cpp:577-585 -- libm on the host, as the reference does, so the last ulp agrees
-            for (uint64_t p = 0; p < n; ++p) {
-                const float x = rp[p];
-                if (x < PHMM_MIN_ACCEPTED_F32)
-                    out_log10[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
-                else
-                    out_log10[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
-            }
+            auto finalize = [&](uint64_t lo, uint64_t hi, unsigned) {
+                for (uint64_t p = lo; p < hi; ++p) {
+                    const float x = rp[p];
+                    if (x < PHMM_MIN_ACCEPTED_F32)
+                        out_log10[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
+                    else
+                        out_log10[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
+                }
+            };
+            if (n >= kParallelMinPairs)
+                parallel_ranges(n, host_threads(), finalize);
+            else
+                finalize(0, n, 0);
         }
     }
     PHASE(6);
