@@ -372,7 +372,7 @@ int pick_cols_per_lane(uint32_t len2, int lanes_per_pair)
             if ((uint32_t)k >= need) return k;
         return 0;
     }
-    for (int k : {2, 3, 4, 8, 16, 32})
+    for (int k : {2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32})
         if ((uint32_t)k >= need) return k;
     return 0;
 }
@@ -398,8 +398,13 @@ hipError_t launch_sw(int cols_per_lane, int lanes_per_pair, const SwArgs &a, hip
             case 2: return launch_one<2, 64>(a, s);
             case 3: return launch_one<3, 64>(a, s);
             case 4: return launch_one<4, 64>(a, s);
+            case 5: return launch_one<5, 64>(a, s);
+            case 6: return launch_one<6, 64>(a, s);
             case 8: return launch_one<8, 64>(a, s);
+            case 10: return launch_one<10, 64>(a, s);
+            case 12: return launch_one<12, 64>(a, s);
             case 16: return launch_one<16, 64>(a, s);
+            case 24: return launch_one<24, 64>(a, s);
             case 32: return launch_one<32, 64>(a, s);
             default: return hipErrorInvalidValue;
         }

@@ -115,7 +115,7 @@ def test_every_geometry_and_long_sequences(aligner, lanes, lds_flags, monkeypatc
     rng = np.random.default_rng(9)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     refs, seqs, pairs = [], [], []
-    for n2 in [1, 2, 3, 31, 32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 193, 224, 225, 255, 256, 257, 300, 511, 512, 513,
+    for n2 in [1, 2, 3, 31, 32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 193, 224, 225, 255, 256, 257, 300, 350, 511, 512, 513, 600,
                700, 1023, 1024, 1025, 1500, 2047]:
         n1 = int(rng.integers(max(1, n2 // 2), min(2047, 2 * n2 + 40) + 1))
         ref = acgt[rng.integers(0, 4, n1)]
