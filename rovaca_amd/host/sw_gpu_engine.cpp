@@ -94,7 +94,7 @@ bool align_now(const SwJob *jobs, size_t n, const sw_parameters &para, SwAlignme
 // Cross-region batching, as for PairHMM (pairhmm_gpu_engine.cpp): the reference's workers realign one region at a time
 // (haplotypecaller_engine.cpp:264), 48 alignments or so -- a dozen waves.  Dispatcher threads merge every request that queued
 // up while the previous device call was in flight into one call and hand each worker its slice.
-// ROVACA_AMD_SW_BATCHING=0 bypasses it (each worker calls the device itself); ROVACA_AMD_SW_DISPATCHERS sets their number (2).
+// ROVACA_AMD_SW_BATCHING=0 bypasses it (each worker calls the device itself); ROVACA_AMD_SW_DISPATCHERS sets their number (1).
 struct Request
 {
     const SwJob *jobs;
@@ -188,7 +188,7 @@ void start_batchers()
     const char *on = getenv("ROVACA_AMD_SW_BATCHING");
     if (on && atoi(on) == 0) return;
     const char *nd = getenv("ROVACA_AMD_SW_DISPATCHERS");
-    int n = nd ? atoi(nd) : 2;
+    int n = nd ? atoi(nd) : 1;  // one: a batch of up to ~2 000 alignments takes as long as one of 48 (lone waves), so merging wins
     n = n < 1 ? 1 : n > 16 ? 16 : n;
     for (int i = 0; i < n; ++i) g_sw_batchers.push_back(new SwBatcher());
 }
