@@ -130,6 +130,7 @@ struct phmm_context
     hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
     struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
     std::vector<uint32_t> bin_hist, bin_slot;  // host scratch of the length binning, kept between calls
+    std::vector<hipEvent_t> timing;            // event pool of phmm_sweep_timed
 };
 
 struct Bin
@@ -314,6 +315,7 @@ void phmm_destroy(phmm_context *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->fork) (void)hipEventDestroy(c->fork);
+    for (hipEvent_t e : c->timing) (void)hipEventDestroy(e);
     for (int i = 0; i < phmm_context::kSideStreams; ++i) {
         if (c->side[i]) (void)hipStreamSynchronize(c->side[i]);
         if (c->join[i]) (void)hipEventDestroy(c->join[i]);
@@ -938,23 +940,35 @@ int phmm_sweep_timed(phmm_context *c, phmm_resident *rb, int iters, double *ms_p
 {
     if (!c || !rb || iters < 1 || !ms_per_pass) return fail(PHMM_E_INVALID, "phmm_sweep_timed: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
+    // three events per pass (start, after the fp32 launches, end), recorded without waiting; the host waits once per group
+    // of passes, so that the passes run back to back as they do without the timing
+    constexpr int kGroup = 32;
+    const int pool = 3 * std::min(iters, kGroup);
+    while ((int)c->timing.size() < pool) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        c->timing.push_back(e);
+    }
     double total = 0.0, fp32 = 0.0;
-    for (int it = 0; it < iters; ++it) {
-        float ms_a = 0.f, ms_b = 0.f;
-        HIP_TRY(hipEventRecord(c->ev0, c->stream));
-        int rc = sweep_fp32(c, rb);
-        if (rc != PHMM_OK) return rc;
-        HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        HIP_TRY(hipEventSynchronize(c->ev1));
-        HIP_TRY(hipEventElapsedTime(&ms_a, c->ev0, c->ev1));
-        HIP_TRY(hipEventRecord(c->ev0, c->stream));
-        rc = sweep_rescue(c, rb);
-        if (rc != PHMM_OK) return rc;
-        HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        HIP_TRY(hipEventSynchronize(c->ev1));
-        HIP_TRY(hipEventElapsedTime(&ms_b, c->ev0, c->ev1));
-        fp32 += ms_a;
-        total += (double)ms_a + ms_b;
+    for (int base = 0; base < iters; base += kGroup) {
+        const int m = std::min(kGroup, iters - base);
+        for (int i = 0; i < m; ++i) {
+            HIP_TRY(hipEventRecord(c->timing[3 * i], c->stream));
+            int rc = sweep_fp32(c, rb);
+            if (rc != PHMM_OK) return rc;
+            HIP_TRY(hipEventRecord(c->timing[3 * i + 1], c->stream));
+            rc = sweep_rescue(c, rb);
+            if (rc != PHMM_OK) return rc;
+            HIP_TRY(hipEventRecord(c->timing[3 * i + 2], c->stream));
+        }
+        HIP_TRY(hipEventSynchronize(c->timing[3 * (m - 1) + 2]));
+        for (int i = 0; i < m; ++i) {
+            float ms_a = 0.f, ms_b = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms_a, c->timing[3 * i], c->timing[3 * i + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms_b, c->timing[3 * i + 1], c->timing[3 * i + 2]));
+            fp32 += ms_a;
+            total += (double)ms_a + ms_b;
+        }
     }
     *ms_per_pass = total / iters;
     if (fp32_ms_per_pass) *fp32_ms_per_pass = fp32 / iters;
