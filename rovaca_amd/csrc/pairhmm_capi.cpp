@@ -125,7 +125,8 @@ struct phmm_context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // the per-K launches of one pass are independent: they are spread over a few side streams so that the tail of one
     // launch overlaps the head of the next (mixed-length batches have up to 17 launches per pass)
-    static constexpr int kSideStreams = 3;
+    static constexpr int kSideStreams = 3;  // created
+    int n_side = 2;                         // used (PHMM_SIDE_STREAMS overrides: tuning; 2 and 3 measure the same, 0 loses 40 % on config 5)
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
     struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
@@ -274,6 +275,7 @@ int phmm_create(int device_id, void *stream, phmm_context **out)
     phmm_context *c = new (std::nothrow) phmm_context();
     if (!c) return fail(PHMM_E_NOMEM, "phmm_create: out of host memory");
     c->device = device_id;
+    if (const char *e = getenv("PHMM_SIDE_STREAMS")) c->n_side = std::max(0, std::min((int)phmm_context::kSideStreams, atoi(e)));
     if (stream) {
         c->stream = static_cast<hipStream_t>(stream);
     }
@@ -749,7 +751,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
     const bool fan_out = rb->bins.size() > 1;
     if (fan_out) {
         HIP_TRY(hipEventRecord(c->fork, c->stream));
-        for (int i = 0; i < phmm_context::kSideStreams; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
+        for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
     }
     // striped launches run side by side on different streams: each gets its own slice of the carry buffer, sized up front
     struct StripedPlan
@@ -774,7 +776,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
     int nth = 0;
     for (size_t i = 0; i < rb->bins.size(); ++i) {
         const Bin &bin = rb->bins[i];
-        const int lane = fan_out ? nth++ % (phmm_context::kSideStreams + 1) : 0;
+        const int lane = fan_out ? nth++ % (c->n_side + 1) : 0;
         hipStream_t stream = lane == 0 ? c->stream : c->side[lane - 1];
         phmm::KernelArgs a{};
         a.read_bases = rb->read_bases.p;
@@ -820,7 +822,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         }
     }
     if (fan_out) {
-        for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+        for (int i = 0; i < c->n_side; ++i) {
             HIP_TRY(hipEventRecord(c->join[i], c->side[i]));
             HIP_TRY(hipStreamWaitEvent(c->stream, c->join[i], 0));
         }
@@ -886,13 +888,13 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
     const bool fan_out = n_active > 1;
     if (fan_out) {
         HIP_TRY(hipEventRecord(c->fork, c->stream));
-        for (int i = 0; i < phmm_context::kSideStreams; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
+        for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
     }
     int nth = 0;
     for (int qi = 0; qi < kQueues; ++qi) {
         const QueuePlan &p = q[qi];
         if (p.cap == 0) continue;
-        const int lane = fan_out ? nth++ % (phmm_context::kSideStreams + 1) : 0;
+        const int lane = fan_out ? nth++ % (c->n_side + 1) : 0;
         hipStream_t st = lane == 0 ? c->stream : c->side[lane - 1];
         phmm::KernelArgs a{};
         a.read_bases = rb->read_bases.p;
@@ -919,7 +921,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
                                          p.max_hap + 1, p.teams, st));
     }
     if (fan_out) {
-        for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+        for (int i = 0; i < c->n_side; ++i) {
             HIP_TRY(hipEventRecord(c->join[i], c->side[i]));
             HIP_TRY(hipStreamWaitEvent(c->stream, c->join[i], 0));
         }
