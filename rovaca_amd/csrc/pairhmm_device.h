@@ -10,7 +10,7 @@ namespace phmm
 constexpr int kLanesPerPair = 16;     // one DPP row per (read, haplotype) pair; four pairs per wave64
 constexpr int kBlockThreads = 256;    // 4 waves = 16 pairs per workgroup
 constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take the single-pass kernel
-constexpr int kMaxRowsPerLaneWide = 4;  // same limit for the one-pair-per-wave shape: 64 * 4 rows
+constexpr int kMaxRowsPerLaneWide = 8;  // the one-pair-per-wave shape goes further: 64 * 8 = 512 rows in one pass
 constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other
 #ifndef PHMM_STRIPED_ROWS_F32
 #define PHMM_STRIPED_ROWS_F32 8

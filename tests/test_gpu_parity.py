@@ -292,6 +292,29 @@ def test_team_kernel_every_width(engine, waves, lanes, monkeypatch):
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
+@pytest.mark.parametrize("wide_single_pass", [True, False])
+def test_reads_of_257_to_512_bases(engine, wide_single_pass, monkeypatch):
+    # still one pass with a whole wave per pair (K = ceil(R/64) up to 8), or the team kernel when that is switched off
+    if not wide_single_pass:
+        monkeypatch.setenv("PHMM_NO_WIDE_SINGLE_PASS", "1")
+    rng = np.random.default_rng(93)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    reads, haps, pairs = [], [], []
+    for R in (257, 300, 320, 321, 384, 385, 400, 448, 449, 500, 512):
+        H = int(rng.integers(R, 2 * R + 100))
+        hap = acgt[rng.integers(0, 4, H)]
+        a = int(rng.integers(0, H - R + 1))
+        seq = hap[a:a + R].copy()
+        seq[rng.random(R) < 0.01] = ord("A")
+        q = rng.choice(np.array([6, 25, 37], np.uint8), R, p=[0.05, 0.15, 0.8])
+        g = np.full(R, 40, np.uint8)
+        reads.append((seq, q, g, g, np.full(R, 10, np.uint8)))
+        haps.append(hap)
+        pairs.append((len(reads) - 1, len(haps) - 1))
+    pairs += [(0, 3), (5, 10), (10, 10)]
+    _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
+
+
 @pytest.mark.parametrize("skip_zero_supersteps", [True, False])
 def test_long_noisy_reads_with_and_without_the_zero_superstep_shortcut(engine, skip_zero_supersteps, monkeypatch):
     # long reads spend most of their sweep on cells that are exactly zero; the team kernel skips supersteps whose inputs and
