@@ -300,7 +300,12 @@ def cpu_baseline(batch, gpu_raw, gpu_l10, threads):
         idx = np.nonzero(acc)[0][:: max(1, int(acc.sum()) // 50000)]
         ref_l10 = np.array([L.phmm_oracle_finalize_f32(float(raw[i])) for i in idx])
         delta = float(np.abs(ref_l10 - gpu_l10[idx]).max()) if idx.size else 0.0
+        # the same kernel on one thread, on 100 regions of the 150 x 300 shape (a third of a second), for the per-core figure
+        from rovaca_amd import synth
+        one = synth.make_batch(seed=77, n_regions=100, reads=40, haps=25, read_len=150, hap_len=300)
+        _, sec1 = oracle.ref_regions_16x1(one, n_threads=1)
         return ({"value": round(cells / sec / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "reference",
+                 "value_1_thread_150x300": round(one.cells() / sec1 / 1e9, 3),
                  "sample": f"all {batch.n_pairs} pairs of the benchmark batch through the reference's "
                            "compute_full_prob_avx512_float_1xn (16 reads x 1 hap), kernel + lane packing, "
                            f"{threads} std::threads, {sec:.2f} s", "bit_identical_to_gpu_fp32": same}, delta)
