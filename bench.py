@@ -252,6 +252,8 @@ def bench_smith_waterman(args, rank, world, device, dist):
                      "algorithmic_bytes": alg_bytes,
                      "note": "integer-VALU bound (DESIGN.md 7); the backtrack flags (4 bits per cell) are the HBM traffic"},
         "call_gcups_pcie_inclusive": round(world * cells * args.steps / call_s / 1e9, 2),
+        "timing": "value: HIP events around the launches inside swhip_align, summed over the steps (the C ABI takes host buffers, "
+                  "there is no resident form); call_gcups_pcie_inclusive: wall clock of the same calls",
     }
     if world == 1 and not args.no_cpu_baseline:
         import oracle  # checker + CPU baseline leg only
