@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PHMM_ABI_VERSION 2
+#define PHMM_ABI_VERSION 3
 
 /* status codes (0 = ok).  Nothing is thrown across this boundary. */
 enum {
@@ -94,7 +94,8 @@ typedef struct phmm_stats {
 /* ---- life cycle (replaces the kernel binding half of init_pairhmm_ptr, pairhmm_engine.cpp:43-52) ---- */
 int phmm_abi_version(void);
 int phmm_device_count(void);
-/* device_id >= 0.  stream: a hipStream_t to run on, or NULL to create a private one. */
+/* device_id >= 0.  stream: a hipStream_t to run on, or NULL to create a private one.  One context drives ONE device (its
+ * stream set, staging and tables live there); for several devices see phmm_create_multi below. */
 int phmm_create(int device_id, void *stream, phmm_context **out);
 void phmm_destroy(phmm_context *ctx);
 const char *phmm_last_error(void); /* thread-local text of the last failure */
@@ -120,6 +121,33 @@ int phmm_download(phmm_context *ctx, phmm_resident *rb, float *out_raw_f32, doub
 int phmm_download_read_table(phmm_context *ctx, phmm_resident *rb, uint8_t *qual, uint8_t *ins, uint8_t *del, uint8_t *gcp);
 int phmm_synchronize(phmm_context *ctx);
 void phmm_release(phmm_context *ctx, phmm_resident *rb);
+
+/* ---- several devices behind one handle ("create(device_ids[], n)"; 8e: plain split, no collective) ----
+ * The reference's call site hands one region at a time to the seam from up to 128 workers (haplotypecaller_engine.cpp:119);
+ * for batch-scale work (BASELINE config 4: ~1e8 pairs over 8 GPUs) the batch is cut instead: pairs sorted by (rows per lane,
+ * haplotype length, index) and divided into n_devices contiguous slices of equal DP cells; every device works its slice on
+ * its own host thread, with its own context (stream set, pinned staging, tables), and writes results at the pairs' own
+ * positions of the caller's arrays.  A phmm_context stays one-device by contract (phmm_create); this handle owns one per
+ * listed device.  device_ids must be distinct. */
+typedef struct phmm_multi phmm_multi;
+typedef struct phmm_multi_resident phmm_multi_resident;
+int phmm_create_multi(const int *device_ids, int n_devices, phmm_multi **out);
+void phmm_destroy_multi(phmm_multi *m);
+int phmm_multi_device_count(const phmm_multi *m);
+int phmm_multi_device_id(const phmm_multi *m, int i); /* HIP device of slice i, -1 when out of range */
+/* one-shot, host buffers in and out, same semantics per pair as phmm_compute; stats are summed (kernel_ms: the slowest device) */
+int phmm_multi_compute(phmm_multi *m, const phmm_batch *batch, float *out_raw_f32, double *out_log10, phmm_stats *stats);
+/* resident form: cut + one upload per device, then passes on all devices */
+int phmm_multi_upload(phmm_multi *m, const phmm_batch *batch, phmm_multi_resident **out);
+int phmm_multi_sweep(phmm_multi *m, phmm_multi_resident *rb); /* enqueue one pass on every device (asynchronous) */
+int phmm_multi_synchronize(phmm_multi *m);
+/* `iters` passes on every device at once, one host thread per device; *wall_ms_per_pass = (slowest device's wall time from
+ * the common start) / iters; device_ms_per_pass / fp32_ms_per_pass (nullable, [n_devices]): HIP-event time of a pass */
+int phmm_multi_sweep_timed(phmm_multi *m, phmm_multi_resident *rb, int iters, double *wall_ms_per_pass, double *device_ms_per_pass,
+                           double *fp32_ms_per_pass);
+int phmm_multi_download(phmm_multi *m, phmm_multi_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats);
+int phmm_multi_shard_cells(const phmm_multi_resident *rb, uint64_t *cells /*[n_devices], nullable*/, uint64_t *pairs /*nullable*/);
+void phmm_multi_release(phmm_multi *m, phmm_multi_resident *rb);
 
 /* ---- lookup tables the engine built on the host (core/context.h:13-189), for parity checks ---- */
 #define PHMM_MM_TABLE_SIZE 32640 /* ((254 + 1) * (254 + 2)) >> 1 */

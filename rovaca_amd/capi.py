@@ -17,7 +17,10 @@ MM_TABLE_SIZE = 32640
 
 EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy", "phmm_last_error", "phmm_compute",
            "phmm_upload", "phmm_sweep", "phmm_sweep_timed", "phmm_download", "phmm_synchronize", "phmm_release",
-           "phmm_get_tables", "phmm_download_read_table")
+           "phmm_get_tables", "phmm_download_read_table",
+           "phmm_create_multi", "phmm_destroy_multi", "phmm_multi_device_count", "phmm_multi_device_id", "phmm_multi_compute",
+           "phmm_multi_upload", "phmm_multi_sweep", "phmm_multi_synchronize", "phmm_multi_sweep_timed", "phmm_multi_download",
+           "phmm_multi_shard_cells", "phmm_multi_release")
 
 
 class PhmmBatch(C.Structure):
@@ -81,6 +84,30 @@ def lib():
     L.phmm_download_read_table.restype = C.c_int
     L.phmm_get_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.phmm_get_tables.restype = C.c_int
+    L.phmm_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.phmm_create_multi.restype = C.c_int
+    L.phmm_destroy_multi.argtypes = [C.c_void_p]
+    L.phmm_destroy_multi.restype = None
+    L.phmm_multi_device_count.argtypes = [C.c_void_p]
+    L.phmm_multi_device_count.restype = C.c_int
+    L.phmm_multi_device_id.argtypes = [C.c_void_p, C.c_int]
+    L.phmm_multi_device_id.restype = C.c_int
+    L.phmm_multi_compute.argtypes = [C.c_void_p, C.POINTER(PhmmBatch), C.c_void_p, C.c_void_p, C.POINTER(PhmmStats)]
+    L.phmm_multi_compute.restype = C.c_int
+    L.phmm_multi_upload.argtypes = [C.c_void_p, C.POINTER(PhmmBatch), C.POINTER(C.c_void_p)]
+    L.phmm_multi_upload.restype = C.c_int
+    L.phmm_multi_sweep.argtypes = [C.c_void_p, C.c_void_p]
+    L.phmm_multi_sweep.restype = C.c_int
+    L.phmm_multi_synchronize.argtypes = [C.c_void_p]
+    L.phmm_multi_synchronize.restype = C.c_int
+    L.phmm_multi_sweep_timed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+    L.phmm_multi_sweep_timed.restype = C.c_int
+    L.phmm_multi_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PhmmStats)]
+    L.phmm_multi_download.restype = C.c_int
+    L.phmm_multi_shard_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.phmm_multi_shard_cells.restype = C.c_int
+    L.phmm_multi_release.argtypes = [C.c_void_p, C.c_void_p]
+    L.phmm_multi_release.restype = None
     _LIB = L
     return L
 
@@ -195,6 +222,92 @@ class Engine:
     def close(self):
         if self.handle:
             lib().phmm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiResident:
+    """A batch cut into equal-cells slices, one resident slice per device (phmm_multi_upload)."""
+
+    def __init__(self, engine, handle, n_pairs):
+        self.engine, self.handle, self.n_pairs = engine, handle, n_pairs
+
+    def sweep(self):
+        _check(lib().phmm_multi_sweep(self.engine.handle, self.handle), "phmm_multi_sweep")
+
+    def sweep_timed(self, iters=1):
+        """(wall ms per pass = slowest device, per-device ms per pass by HIP events, per-device fp32 kernel ms)."""
+        n = self.engine.n_devices
+        wall = C.c_double()
+        dev, f32 = np.zeros(n, np.float64), np.zeros(n, np.float64)
+        _check(lib().phmm_multi_sweep_timed(self.engine.handle, self.handle, iters, C.byref(wall), _ptr(dev), _ptr(f32)),
+               "phmm_multi_sweep_timed")
+        return wall.value, dev, f32
+
+    def shard_cells(self):
+        n = self.engine.n_devices
+        cells, pairs = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        _check(lib().phmm_multi_shard_cells(self.handle, _ptr(cells), _ptr(pairs)), "phmm_multi_shard_cells")
+        return cells, pairs
+
+    def download(self):
+        raw = np.zeros(self.n_pairs, np.float32)
+        l10 = np.zeros(self.n_pairs, np.float64)
+        st = PhmmStats()
+        _check(lib().phmm_multi_download(self.engine.handle, self.handle, _ptr(raw), _ptr(l10), C.byref(st)), "phmm_multi_download")
+        return raw, l10, st
+
+    def release(self):
+        if self.handle:
+            lib().phmm_multi_release(self.engine.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class MultiEngine:
+    """Several devices behind one handle (phmm_create_multi): the pair list is cut into equal-cells slices, one host thread
+    and one context per device, no collective."""
+
+    def __init__(self, devices):
+        devices = [int(d) for d in devices]
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib().phmm_create_multi(arr, len(devices), C.byref(h)), "phmm_create_multi")
+        self.handle = h
+        self.n_devices = lib().phmm_multi_device_count(h)
+        self.devices = [lib().phmm_multi_device_id(h, i) for i in range(self.n_devices)]
+
+    def compute(self, batch, cross=False, prep=None):
+        cb = _c_batch(batch, cross, prep)
+        n = batch.n_reads * batch.n_haps if cross else batch.n_pairs
+        raw = np.zeros(n, np.float32)
+        l10 = np.zeros(n, np.float64)
+        st = PhmmStats()
+        _check(lib().phmm_multi_compute(self.handle, C.byref(cb), _ptr(raw), _ptr(l10), C.byref(st)), "phmm_multi_compute")
+        return raw, l10, st
+
+    def upload(self, batch, cross=False, prep=None):
+        cb = _c_batch(batch, cross, prep)
+        h = C.c_void_p()
+        _check(lib().phmm_multi_upload(self.handle, C.byref(cb), C.byref(h)), "phmm_multi_upload")
+        return MultiResident(self, h, batch.n_reads * batch.n_haps if cross else batch.n_pairs)
+
+    def synchronize(self):
+        _check(lib().phmm_multi_synchronize(self.handle), "phmm_multi_synchronize")
+
+    def close(self):
+        if self.handle:
+            lib().phmm_destroy_multi(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -11,7 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <exception>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -229,8 +231,19 @@ template <typename F>
 static void parallel_ranges(uint64_t n, unsigned n_threads, F &&fn)  // fn(lo, hi, thread index)
 {
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
+    th.reserve(n_threads);
+    unsigned started = 1;  // ranges [1, started) run on helper threads; the rest on the caller (a process with 128 workers may
+                           // be out of threads: std::thread then throws, and the work is done here instead)
+    try {
+        for (; started < n_threads; ++started) {
+            const unsigned t = started;
+            th.emplace_back([&fn, n, n_threads, t] { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
+        }
+    }
+    catch (...) {
+    }
     fn(0, n / n_threads, 0u);
+    for (unsigned t = started; t < n_threads; ++t) fn(n * t / n_threads, n * (t + 1) / n_threads, t);
     for (auto &x : th) x.join();
 }
 static unsigned host_threads()
@@ -240,11 +253,12 @@ static unsigned host_threads()
 }
 
 
-extern "C" {
-
-int phmm_abi_version(void) { return PHMM_ABI_VERSION; }
-
-const char *phmm_last_error(void) { return g_err; }
+// The entry points are implemented in this namespace with C++ linkage; the extern "C" wrappers at the end of the file
+// catch whatever a body may throw (std::bad_alloc from a vector, std::system_error from a thread), so that nothing
+// crosses the C boundary (include/pairhmm_hip.h).
+namespace impl
+{
+void phmm_destroy(phmm_context *c);
 
 int phmm_device_count(void)
 {
@@ -302,7 +316,7 @@ int phmm_create(int device_id, void *stream, phmm_context **out)
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
-        phmm_destroy(c);
+        impl::phmm_destroy(c);
         return fail(PHMM_E_HIP, "phmm_create: table upload failed: %s", hipGetErrorString(e));
     }
     *out = c;
@@ -1072,15 +1086,19 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
     }
     phmm_resident *rb = c->scratch;
     PhaseClock clock;
-    g_phase = clock.on ? &clock : nullptr;
+    struct PhaseScope  // the thread-local pointer never outlives the clock it points to, whichever way the call returns
+    {
+        explicit PhaseScope(PhaseClock *p) { g_phase = p; }
+        ~PhaseScope() { g_phase = nullptr; }
+    } phase_scope(clock.on ? &clock : nullptr);
     int rc = upload_into(c, b, rb);
     if (rc != PHMM_OK) return rc;
     // one pass; the events are read only after the download's synchronisation (no extra round trip for the timing)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    rc = phmm_sweep(c, rb);
+    rc = impl::phmm_sweep(c, rb);
     if (rc != PHMM_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    rc = phmm_download(c, rb, out_raw_f32, out_log10, stats);
+    rc = impl::phmm_download(c, rb, out_raw_f32, out_log10, stats);
     if (rc == PHMM_OK && stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -1093,9 +1111,451 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
         PHASE(7);
         fprintf(stderr, "phmm phases us: validate %.1f pack %.1f bin %.1f enqueue-upload %.1f enqueue-sweep %.1f wait %.1f finalize %.1f stats %.1f\n",
                 clock.us[0], clock.us[1], clock.us[2], clock.us[3], clock.us[4], clock.us[5], clock.us[6], clock.us[7]);
-        g_phase = nullptr;
     }
     return rc;
+}
+
+}  // namespace impl
+
+// ----------------------------------------------------------------------------------------------------
+// Several devices behind one handle (SURVEY.md 8b "create(device_ids[], n)", 8e): pairs are independent, so a batch is cut
+// into one slice per device -- contiguous ranges of the length-binned order (rows per lane, haplotype length, pair index),
+// equal in DP cells, not in pairs -- and every device works its slice on its own host thread with its own context (stream
+// set, staging, tables).  There is no exchange step and no collective; results land at the pairs' own positions of the
+// caller's arrays, which are disjoint between devices.
+// ----------------------------------------------------------------------------------------------------
+struct phmm_multi
+{
+    std::vector<phmm_context *> ctx;
+};
+
+struct phmm_multi_resident
+{
+    uint64_t n_pairs = 0;
+    std::vector<phmm_resident *> part;            // one per device (never null; a slice may be empty)
+    std::vector<std::vector<uint32_t>> index;     // pair ids of each slice, in slice order
+    std::vector<std::vector<uint32_t>> pr, ph;    // the slices' pair lists (kept: phmm_upload_into copies them, but cheap)
+    std::vector<uint64_t> cells;
+};
+
+namespace impl
+{
+
+// run fn(device index) on one thread per device; the first failure's status and text are handed to the calling thread
+template <typename F>
+static int on_every_device(phmm_multi *m, F &&fn)
+{
+    const size_t n = m->ctx.size();
+    std::vector<int> rc(n, PHMM_OK);
+    std::vector<std::string> msg(n);
+    auto body = [&](size_t g) {
+        try {
+            rc[g] = fn(g);
+        }
+        catch (const std::bad_alloc &) {
+            rc[g] = fail(PHMM_E_NOMEM, "out of host memory on the thread of device %d", m->ctx[g]->device);
+        }
+        catch (...) {
+            rc[g] = fail(PHMM_E_INVALID, "unexpected exception on the thread of device %d", m->ctx[g]->device);
+        }
+        if (rc[g] != PHMM_OK) msg[g] = g_err;  // g_err is thread-local: copy it out of the worker
+    };
+    std::vector<std::thread> th;
+    th.reserve(n);
+    size_t started = 1;
+    try {
+        for (; started < n; ++started) th.emplace_back(body, started);
+    }
+    catch (...) {
+    }
+    body(0);
+    for (size_t g = started; g < n; ++g) body(g);
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < n; ++g)
+        if (rc[g] != PHMM_OK) return fail(rc[g], "device %d: %s", m->ctx[g]->device, msg[g].c_str());
+    return PHMM_OK;
+}
+
+void phmm_destroy_multi(phmm_multi *m)
+{
+    if (!m) return;
+    for (phmm_context *c : m->ctx) impl::phmm_destroy(c);
+    delete m;
+}
+
+int phmm_create_multi(const int *device_ids, int n_devices, phmm_multi **out)
+{
+    if (!out || !device_ids || n_devices < 1) return fail(PHMM_E_INVALID, "phmm_create_multi: bad arguments");
+    *out = nullptr;
+    for (int i = 0; i < n_devices; ++i)
+        for (int j = 0; j < i; ++j)
+            if (device_ids[i] == device_ids[j])
+                return fail(PHMM_E_INVALID, "phmm_create_multi: device %d is listed twice (one context per device)", device_ids[i]);
+    phmm_multi *m = new phmm_multi();
+    for (int i = 0; i < n_devices; ++i) {
+        phmm_context *c = nullptr;
+        const int rc = impl::phmm_create(device_ids[i], nullptr, &c);
+        if (rc != PHMM_OK) {
+            impl::phmm_destroy_multi(m);
+            return rc;
+        }
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return PHMM_OK;
+}
+
+void phmm_multi_release(phmm_multi *m, phmm_multi_resident *rb)
+{
+    if (!rb) return;
+    for (size_t g = 0; g < rb->part.size(); ++g) impl::phmm_release(m && g < m->ctx.size() ? m->ctx[g] : nullptr, rb->part[g]);
+    delete rb;
+}
+
+// the cut: pairs sorted by (rows per lane = ceil(R / 16), haplotype length, index), then n contiguous slices of near-equal
+// cells (each cut within one pair of the ideal)
+static int partition_equal_cells(const phmm_batch *b, size_t n_dev, phmm_multi_resident *rb)
+{
+    if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
+        return fail(PHMM_E_INVALID, "phmm_multi_upload: pair_read and pair_hap must both be given or both be NULL");
+    const bool cross = b->pair_read == nullptr;
+    const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
+    if (n > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_multi_upload: more than 2^32 pairs in one batch");
+    if (n && (!b->read_len || !b->hap_len)) return fail(PHMM_E_INVALID, "phmm_multi_upload: null table pointer");
+    rb->n_pairs = n;
+    std::vector<uint64_t> keys(n);
+    std::atomic<uint64_t> bad{UINT64_MAX};
+    auto pair_of = [&](uint64_t p, uint32_t &r, uint32_t &h) {
+        if (cross) {
+            r = (uint32_t)(p / b->n_haps);
+            h = (uint32_t)(p % b->n_haps);
+        }
+        else {
+            r = b->pair_read[p];
+            h = b->pair_hap[p];
+        }
+    };
+    const unsigned T = n >= kParallelMinPairs ? host_threads() : 1u;
+    parallel_ranges(n, T, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t p = lo; p < hi; ++p) {
+            uint32_t r, h;
+            pair_of(p, r, h);
+            if (r >= b->n_reads || h >= b->n_haps) {
+                uint64_t expect = UINT64_MAX;
+                bad.compare_exchange_strong(expect, p);
+                return;
+            }
+            const uint64_t k = (b->read_len[r] + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
+            keys[p] = (k << 52) | ((uint64_t)(b->hap_len[h] & 0xFFFFFu) << 32) | p;  // lengths were checked < 2^20 by upload
+        }
+    });
+    if (bad.load() != UINT64_MAX)
+        return fail(PHMM_E_INVALID, "phmm_multi_upload: pair %llu indexes outside the tables", (unsigned long long)bad.load());
+    std::sort(keys.begin(), keys.end());
+    std::vector<uint64_t> cum(n);
+    uint64_t run = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t r, h;
+        pair_of(keys[i] & 0xFFFFFFFFull, r, h);
+        run += (uint64_t)b->read_len[r] * b->hap_len[h];
+        cum[i] = run;
+    }
+    rb->index.assign(n_dev, {});
+    rb->pr.assign(n_dev, {});
+    rb->ph.assign(n_dev, {});
+    rb->cells.assign(n_dev, 0);
+    uint64_t prev = 0;
+    for (size_t g = 0; g < n_dev; ++g) {
+        uint64_t cut = n;
+        if (g + 1 < n_dev) {
+            const long double target = (long double)run * (long double)(g + 1) / (long double)n_dev;
+            cut = (uint64_t)(std::lower_bound(cum.begin(), cum.end(), target, [](uint64_t c, long double t) { return (long double)c < t; }) - cum.begin());
+            cut = std::max(cut, prev);
+        }
+        rb->index[g].resize(cut - prev);
+        rb->pr[g].resize(cut - prev);
+        rb->ph[g].resize(cut - prev);
+        for (uint64_t i = prev; i < cut; ++i) {
+            const uint32_t p = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+            uint32_t r, h;
+            pair_of(p, r, h);
+            rb->index[g][i - prev] = p;
+            rb->pr[g][i - prev] = r;
+            rb->ph[g][i - prev] = h;
+        }
+        rb->cells[g] = (cut ? cum[cut - 1] : 0) - (prev ? cum[prev - 1] : 0);
+        prev = cut;
+    }
+    return PHMM_OK;
+}
+
+static phmm_batch slice_of(const phmm_batch *b, const phmm_multi_resident *rb, size_t g)
+{
+    phmm_batch s = *b;
+    s.n_pairs = rb->index[g].size();
+    // an empty slice still needs non-null pair arrays, or it would read as "full cross product"
+    static const uint32_t none = 0;
+    s.pair_read = rb->pr[g].empty() ? &none : rb->pr[g].data();
+    s.pair_hap = rb->ph[g].empty() ? &none : rb->ph[g].data();
+    return s;
+}
+
+int phmm_multi_upload(phmm_multi *m, const phmm_batch *b, phmm_multi_resident **out)
+{
+    if (!m || !b || !out) return fail(PHMM_E_INVALID, "phmm_multi_upload: null argument");
+    *out = nullptr;
+    phmm_multi_resident *rb = new phmm_multi_resident();
+    int rc = partition_equal_cells(b, m->ctx.size(), rb);
+    if (rc == PHMM_OK) {
+        rb->part.assign(m->ctx.size(), nullptr);
+        rc = on_every_device(m, [&](size_t g) {
+            const phmm_batch s = slice_of(b, rb, g);
+            return impl::phmm_upload(m->ctx[g], &s, &rb->part[g]);
+        });
+    }
+    if (rc != PHMM_OK) {
+        impl::phmm_multi_release(m, rb);
+        return rc;
+    }
+    *out = rb;
+    return PHMM_OK;
+}
+
+int phmm_multi_sweep(phmm_multi *m, phmm_multi_resident *rb)
+{
+    if (!m || !rb) return fail(PHMM_E_INVALID, "phmm_multi_sweep: null argument");
+    // enqueue only (asynchronous): cheap enough to do from the calling thread, device after device
+    for (size_t g = 0; g < m->ctx.size(); ++g) {
+        const int rc = impl::phmm_sweep(m->ctx[g], rb->part[g]);
+        if (rc != PHMM_OK) return rc;
+    }
+    return PHMM_OK;
+}
+
+int phmm_multi_synchronize(phmm_multi *m)
+{
+    if (!m) return fail(PHMM_E_INVALID, "phmm_multi_synchronize: null argument");
+    for (phmm_context *c : m->ctx) {
+        const int rc = impl::phmm_synchronize(c);
+        if (rc != PHMM_OK) return rc;
+    }
+    return PHMM_OK;
+}
+
+int phmm_multi_sweep_timed(phmm_multi *m, phmm_multi_resident *rb, int iters, double *wall_ms_per_pass, double *device_ms_per_pass,
+                           double *fp32_ms_per_pass)
+{
+    if (!m || !rb || iters < 1 || !wall_ms_per_pass) return fail(PHMM_E_INVALID, "phmm_multi_sweep_timed: bad arguments");
+    const size_t n = m->ctx.size();
+    // every device thread waits at the gate, sweeps `iters` passes bracketed by HIP events on its own stream and reports its
+    // wall time from the common start; the job's time is the slowest device's
+    std::atomic<size_t> arrived{0};
+    std::atomic<bool> go{false};
+    std::chrono::steady_clock::time_point t_start;
+    std::vector<double> wall(n, 0.0), dev(n, 0.0), f32(n, 0.0);
+    const int rc = on_every_device(m, [&](size_t g) {
+        int r = impl::phmm_synchronize(m->ctx[g]);
+        if (arrived.fetch_add(1) + 1 == n) {
+            t_start = std::chrono::steady_clock::now();
+            go.store(true, std::memory_order_release);
+        }
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        if (r != PHMM_OK) return r;
+        r = impl::phmm_sweep_timed(m->ctx[g], rb->part[g], iters, &dev[g], &f32[g]);
+        if (r == PHMM_OK) r = impl::phmm_synchronize(m->ctx[g]);
+        wall[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        return r;
+    });
+    if (rc != PHMM_OK) return rc;
+    double w = 0.0;
+    for (size_t g = 0; g < n; ++g) w = std::max(w, wall[g]);
+    *wall_ms_per_pass = w / iters;
+    for (size_t g = 0; g < n; ++g) {
+        if (device_ms_per_pass) device_ms_per_pass[g] = dev[g];
+        if (fp32_ms_per_pass) fp32_ms_per_pass[g] = f32[g];
+    }
+    return PHMM_OK;
+}
+
+int phmm_multi_download(phmm_multi *m, phmm_multi_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats)
+{
+    if (!m || !rb) return fail(PHMM_E_INVALID, "phmm_multi_download: null argument");
+    const size_t n = m->ctx.size();
+    std::vector<phmm_stats> st(n);
+    const int rc = on_every_device(m, [&](size_t g) -> int {
+        const size_t k = rb->index[g].size();
+        std::vector<float> raw(out_raw_f32 ? k : 0);
+        std::vector<double> l10(out_log10 ? k : 0);
+        const int r = impl::phmm_download(m->ctx[g], rb->part[g], out_raw_f32 ? raw.data() : nullptr, out_log10 ? l10.data() : nullptr, &st[g]);
+        if (r != PHMM_OK) return r;
+        const uint32_t *idx = rb->index[g].data();
+        if (out_raw_f32)
+            for (size_t i = 0; i < k; ++i) out_raw_f32[idx[i]] = raw[i];
+        if (out_log10)
+            for (size_t i = 0; i < k; ++i) out_log10[idx[i]] = l10[i];
+        return PHMM_OK;
+    });
+    if (rc != PHMM_OK) return rc;
+    if (stats) {
+        *stats = phmm_stats{};
+        for (size_t g = 0; g < n; ++g) {
+            stats->cells += st[g].cells;
+            stats->n_rescued += st[g].n_rescued;
+            stats->kernel_ms = std::max(stats->kernel_ms, st[g].kernel_ms);
+            stats->n_launches += st[g].n_launches;
+            stats->max_rows_per_lane = std::max(stats->max_rows_per_lane, st[g].max_rows_per_lane);
+        }
+    }
+    return PHMM_OK;
+}
+
+int phmm_multi_compute(phmm_multi *m, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats)
+{
+    if (!m || !b) return fail(PHMM_E_INVALID, "phmm_multi_compute: null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    phmm_multi_resident part;  // only the cut lives here; every device computes through its context's own scratch batch
+    int rc = partition_equal_cells(b, m->ctx.size(), &part);
+    if (rc != PHMM_OK) return rc;
+    const size_t n = m->ctx.size();
+    std::vector<phmm_stats> st(n);
+    rc = on_every_device(m, [&](size_t g) -> int {
+        const phmm_batch s = slice_of(b, &part, g);
+        const size_t k = part.index[g].size();
+        std::vector<float> raw(out_raw_f32 ? k : 0);
+        std::vector<double> l10(out_log10 ? k : 0);
+        const int r = impl::phmm_compute(m->ctx[g], &s, out_raw_f32 ? raw.data() : nullptr, out_log10 ? l10.data() : nullptr, &st[g]);
+        if (r != PHMM_OK) return r;
+        const uint32_t *idx = part.index[g].data();
+        if (out_raw_f32)
+            for (size_t i = 0; i < k; ++i) out_raw_f32[idx[i]] = raw[i];
+        if (out_log10)
+            for (size_t i = 0; i < k; ++i) out_log10[idx[i]] = l10[i];
+        return PHMM_OK;
+    });
+    if (rc != PHMM_OK) return rc;
+    if (stats) {
+        *stats = phmm_stats{};
+        for (size_t g = 0; g < n; ++g) {
+            stats->cells += st[g].cells;
+            stats->n_rescued += st[g].n_rescued;
+            stats->kernel_ms = std::max(stats->kernel_ms, st[g].kernel_ms);
+            stats->n_launches += st[g].n_launches;
+            stats->max_rows_per_lane = std::max(stats->max_rows_per_lane, st[g].max_rows_per_lane);
+        }
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return PHMM_OK;
+}
+
+}  // namespace impl
+
+// ----------------------------------------------------------------------------------------------------
+// the C boundary: nothing is thrown across it
+// ----------------------------------------------------------------------------------------------------
+namespace
+{
+template <typename F>
+int guarded(const char *what, F &&fn)
+{
+    try {
+        return fn();
+    }
+    catch (const std::bad_alloc &) {
+        return fail(PHMM_E_NOMEM, "%s: out of host memory", what);
+    }
+    catch (const std::exception &e) {
+        return fail(PHMM_E_INVALID, "%s: %s", what, e.what());
+    }
+    catch (...) {
+        return fail(PHMM_E_INVALID, "%s: unexpected exception", what);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int phmm_abi_version(void) { return PHMM_ABI_VERSION; }
+const char *phmm_last_error(void) { return g_err; }
+int phmm_device_count(void) { return impl::phmm_device_count(); }
+int phmm_get_tables(float *a, float *b, double *c, double *d)
+{
+    return guarded("phmm_get_tables", [&] { return impl::phmm_get_tables(a, b, c, d); });
+}
+int phmm_create(int device_id, void *stream, phmm_context **out)
+{
+    return guarded("phmm_create", [&] { return impl::phmm_create(device_id, stream, out); });
+}
+void phmm_destroy(phmm_context *c)
+{
+    (void)guarded("phmm_destroy", [&] { impl::phmm_destroy(c); return PHMM_OK; });
+}
+int phmm_synchronize(phmm_context *c) { return guarded("phmm_synchronize", [&] { return impl::phmm_synchronize(c); }); }
+void phmm_release(phmm_context *c, phmm_resident *rb)
+{
+    (void)guarded("phmm_release", [&] { impl::phmm_release(c, rb); return PHMM_OK; });
+}
+int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
+{
+    return guarded("phmm_upload", [&] { return impl::phmm_upload(c, b, out); });
+}
+int phmm_sweep(phmm_context *c, phmm_resident *rb) { return guarded("phmm_sweep", [&] { return impl::phmm_sweep(c, rb); }); }
+int phmm_sweep_timed(phmm_context *c, phmm_resident *rb, int iters, double *ms, double *ms32)
+{
+    return guarded("phmm_sweep_timed", [&] { return impl::phmm_sweep_timed(c, rb, iters, ms, ms32); });
+}
+int phmm_download(phmm_context *c, phmm_resident *rb, float *raw, double *l10, phmm_stats *st)
+{
+    return guarded("phmm_download", [&] { return impl::phmm_download(c, rb, raw, l10, st); });
+}
+int phmm_download_read_table(phmm_context *c, phmm_resident *rb, uint8_t *q, uint8_t *i, uint8_t *d, uint8_t *g)
+{
+    return guarded("phmm_download_read_table", [&] { return impl::phmm_download_read_table(c, rb, q, i, d, g); });
+}
+int phmm_compute(phmm_context *c, const phmm_batch *b, float *raw, double *l10, phmm_stats *st)
+{
+    return guarded("phmm_compute", [&] { return impl::phmm_compute(c, b, raw, l10, st); });
+}
+
+int phmm_create_multi(const int *device_ids, int n, phmm_multi **out)
+{
+    return guarded("phmm_create_multi", [&] { return impl::phmm_create_multi(device_ids, n, out); });
+}
+void phmm_destroy_multi(phmm_multi *m)
+{
+    (void)guarded("phmm_destroy_multi", [&] { impl::phmm_destroy_multi(m); return PHMM_OK; });
+}
+int phmm_multi_device_count(const phmm_multi *m) { return m ? (int)m->ctx.size() : 0; }
+int phmm_multi_device_id(const phmm_multi *m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[i]->device : -1; }
+int phmm_multi_compute(phmm_multi *m, const phmm_batch *b, float *raw, double *l10, phmm_stats *st)
+{
+    return guarded("phmm_multi_compute", [&] { return impl::phmm_multi_compute(m, b, raw, l10, st); });
+}
+int phmm_multi_upload(phmm_multi *m, const phmm_batch *b, phmm_multi_resident **out)
+{
+    return guarded("phmm_multi_upload", [&] { return impl::phmm_multi_upload(m, b, out); });
+}
+int phmm_multi_sweep(phmm_multi *m, phmm_multi_resident *rb) { return guarded("phmm_multi_sweep", [&] { return impl::phmm_multi_sweep(m, rb); }); }
+int phmm_multi_synchronize(phmm_multi *m) { return guarded("phmm_multi_synchronize", [&] { return impl::phmm_multi_synchronize(m); }); }
+int phmm_multi_sweep_timed(phmm_multi *m, phmm_multi_resident *rb, int iters, double *wall_ms, double *dev_ms, double *f32_ms)
+{
+    return guarded("phmm_multi_sweep_timed", [&] { return impl::phmm_multi_sweep_timed(m, rb, iters, wall_ms, dev_ms, f32_ms); });
+}
+int phmm_multi_download(phmm_multi *m, phmm_multi_resident *rb, float *raw, double *l10, phmm_stats *st)
+{
+    return guarded("phmm_multi_download", [&] { return impl::phmm_multi_download(m, rb, raw, l10, st); });
+}
+int phmm_multi_shard_cells(const phmm_multi_resident *rb, uint64_t *cells, uint64_t *pairs)
+{
+    if (!rb) return fail(PHMM_E_INVALID, "phmm_multi_shard_cells: null argument");
+    for (size_t g = 0; g < rb->cells.size(); ++g) {
+        if (cells) cells[g] = rb->cells[g];
+        if (pairs) pairs[g] = rb->index[g].size();
+    }
+    return PHMM_OK;
+}
+void phmm_multi_release(phmm_multi *m, phmm_multi_resident *rb)
+{
+    (void)guarded("phmm_multi_release", [&] { impl::phmm_multi_release(m, rb); return PHMM_OK; });
 }
 
 }  // extern "C"

@@ -1,0 +1,221 @@
+"""The sharded path with the HIP engine as the per-slice compute, the multi-device handle of the C ABI
+(include/pairhmm_hip.h: phmm_create_multi), BASELINE config 4's chunked resident form and the corner of config 5.
+
+The sharded result must be the unsharded one BIT FOR BIT: a pair's value does not depend on which pairs travel with it
+(H6 note of SURVEY.md 8a; the reference's 16-lane grouping is an AVX artefact)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from rovaca_amd import capi, shard, synth
+from rovaca_amd.batch import Batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+def _mixed_batch():
+    return synth.make_batch(seed=41, n_regions=30, reads=24, haps=7, read_len=(40, 250), hap_len=(100, 500))
+
+
+def test_compute_sharded_world1_with_the_hip_engine(engine):
+    b = _mixed_batch()
+    raw, l10, _ = engine.compute(b)
+
+    def fn(sub):
+        r, l, _ = engine.compute(sub)
+        return r, l
+
+    idx, sraw, sl10 = shard.compute_sharded(b, fn, 0, 1)
+    assert np.array_equal(np.sort(idx), np.arange(b.n_pairs))
+    assert np.array_equal(sraw.view(np.uint32), raw[idx].view(np.uint32)) and np.array_equal(sl10, l10[idx])
+    # every slice of a three-way cut, computed one after the other on this card, lands where the unsharded run put it
+    out = np.zeros(b.n_pairs, np.float32)
+    for rank in range(3):
+        i, r, _ = shard.compute_sharded(b, fn, rank, 3)
+        out[i] = r
+    assert np.array_equal(out.view(np.uint32), raw.view(np.uint32))
+
+
+_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch.distributed as dist
+from rovaca_amd import capi, shard, synth
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)  # the gather only; the data path has no collective
+b = synth.make_batch(seed=41, n_regions=30, reads=24, haps=7, read_len=(40, 250), hap_len=(100, 500))
+eng = capi.Engine(0)  # both ranks share the one card of the test box
+def fn(sub):
+    r, l, _ = eng.compute(sub)
+    return r, l
+raw, l10 = shard.compute_sharded(b, fn, rank, world, dist)
+if rank == 0:
+    np.savez(sys.argv[4], raw=raw, l10=l10)
+dist.barrier()
+eng.close()
+dist.destroy_process_group()
+"""
+
+
+def test_compute_sharded_two_ranks_sharing_the_card(engine, tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT))
+    out = tmp_path / "gathered.npz"
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(port), str(out)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    b = _mixed_batch()
+    raw, l10, _ = engine.compute(b)
+    assert np.array_equal(got["raw"].view(np.uint32), raw.view(np.uint32))
+    assert np.array_equal(got["l10"], l10)
+
+
+def test_multi_device_handle(engine):
+    # the C-ABI form of the same split (one host thread and one context per device); a 1-GPU box exercises it with one slice,
+    # and with as many as there are devices elsewhere
+    n_dev = capi.lib().phmm_device_count()
+    b = _mixed_batch()
+    raw, l10, st = engine.compute(b)
+    for n in sorted({1, n_dev}):
+        m = capi.MultiEngine(list(range(n)))
+        assert m.n_devices == n and m.devices == list(range(n))
+        mraw, ml10, mst = m.compute(b)
+        assert np.array_equal(mraw.view(np.uint32), raw.view(np.uint32)) and np.array_equal(ml10, l10)
+        assert int(mst.cells) == b.cells() and int(mst.n_rescued) == int(st.n_rescued)
+        rb = m.upload(b)
+        cells, pairs = rb.shard_cells()
+        assert int(cells.sum()) == b.cells() and int(pairs.sum()) == b.n_pairs
+        assert int(cells.max()) - int(cells.min()) <= 2 * 250 * 500  # each cut within one pair of the ideal
+        rb.sweep()
+        wall, dev, f32 = rb.sweep_timed(2)
+        assert wall > 0 and (dev > 0).all()
+        rraw, rl10, _ = rb.download()
+        assert np.array_equal(rraw.view(np.uint32), raw.view(np.uint32)) and np.array_equal(rl10, l10)
+        rb.release()
+        # the full cross product form (pair arrays NULL) goes through the same cut
+        cross = Batch(b.read_bases, b.read_qual, b.read_ins, b.read_del, b.read_gcp, b.read_off[:40], b.read_len[:40],
+                      b.hap_bases, b.hap_off[:9], b.hap_len[:9], np.repeat(np.arange(40), 9), np.tile(np.arange(9), 40))
+        craw, _, _ = m.compute(cross, cross=True)
+        eraw, _, _ = engine.compute(cross)
+        assert np.array_equal(craw.view(np.uint32), eraw.view(np.uint32))
+        m.close()
+    with pytest.raises(capi.PhmmError):
+        capi.MultiEngine([0, 0])  # one context per device
+    with pytest.raises(capi.PhmmError):
+        capi.MultiEngine([n_dev])  # no such device
+
+
+def test_bench_refuses_more_gpus_than_there_are():
+    n_dev = capi.lib().phmm_device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_dev + 1), "--steps", "1", "--warmup", "0",
+                        "--scale", "0.01", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_dev + 1), "--oversubscribe", "--steps", "2",
+                        "--warmup", "1", "--scale", "0.02", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == n_dev and line["metric"] == "PairHMM GCUPS" and line["value"] > 0
+
+
+def test_config4_chunked_resident_batch(engine):
+    # BASELINE config 4 as bench.py --config c4 runs it on one GPU: the pair stream is kept resident in chunks (one upload
+    # each), a step sweeps every chunk.  Two chunks of config 4's length distribution here; a seeded sample of every chunk
+    # against the oracle, and the order of the pair list must not matter.
+    chunks = [synth.make_batch(**dict(synth.CONFIGS["c4"], n_regions=120, seed=4 + 7919 * k)) for k in range(2)]
+    residents = [engine.upload(b) for b in chunks]
+    for _ in range(2):  # two steps: results of a pass do not depend on the one before
+        for r in residents:
+            r.sweep()
+    rng = np.random.default_rng(44)
+    for b, r in zip(chunks, residents):
+        raw, l10, st = r.download()
+        assert int(st.cells) == b.cells()
+        idx = np.sort(rng.choice(b.n_pairs, 6000, replace=False))
+        oraw, ol10, oresc = oracle.batch(b.subset(idx), n_threads=8)
+        assert np.array_equal(raw[idx].view(np.uint32), oraw.view(np.uint32))
+        assert np.array_equal(l10[idx][~oresc], ol10[~oresc])
+        perm = rng.permutation(b.n_pairs)
+        rp = engine.upload(b.subset(perm))
+        rp.sweep()
+        praw, pl10, _ = rp.download()
+        rp.release()
+        assert np.array_equal(praw.view(np.uint32), raw[perm].view(np.uint32)) and np.array_equal(pl10, l10[perm], equal_nan=True)
+        r.release()
+    # the same stream cut across devices instead of chunks
+    m = capi.MultiEngine(list(range(capi.lib().phmm_device_count())))
+    mraw, _, _ = m.compute(chunks[0])
+    eraw, _, _ = engine.compute(chunks[0])
+    assert np.array_equal(mraw.view(np.uint32), eraw.view(np.uint32))
+    m.close()
+
+
+def _long_pair(rng, R, H, sub_rate=0.01):
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, H)]
+    a = int(rng.integers(0, H - R + 1))
+    seq = hap[a:a + R].copy()
+    sub = rng.random(R) < sub_rate
+    seq[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+    q = rng.choice(np.array([6, 25, 37], np.uint8), R, p=[0.05, 0.15, 0.8])
+    g = np.full(R, 40, np.uint8)
+    return (seq, q, g, g, np.full(R, 10, np.uint8)), hap
+
+
+def test_config5_corner_10k_by_12k(engine):
+    # the corner of BASELINE config 5: the longest read against the longest haplotype (largest carry slab, largest LDS plane
+    # staging, the dynamic-LDS attribute path) and a short read against it.  The reference sizes its row buffers as VLAs on
+    # the stack for this (core/avx512_s.cpp:269-277); here the carry lives in HBM.
+    rng = np.random.default_rng(55)
+    reads, haps = [], []
+    for R, H in ((10000, 12000), (2000, 12000)):
+        rd, hp = _long_pair(rng, R, H)
+        reads.append(rd)
+        haps.append(hp)
+    b = Batch.from_lists(reads, haps, [(0, 0), (1, 1), (1, 0)])
+    raw, l10, st = engine.compute(b)
+    oraw, ol10, oresc = oracle.batch(b, n_threads=3)
+    assert np.array_equal(raw.view(np.uint32), oraw.view(np.uint32))
+    assert np.array_equal(np.isfinite(l10), np.isfinite(ol10))
+    fin = np.isfinite(ol10)
+    assert np.array_equal(l10[fin], ol10[fin])
+    assert int(st.n_rescued) == int(oresc.sum())
+
+
+def test_config5_full_size_properties(engine, monkeypatch):
+    # all 1 000 pairs of config 5 (the oracle would need hours): every result finite or -inf and never NaN, the same bits in
+    # any pair order, and the same bits with the zero-superstep shortcut switched off
+    b = synth.make_config("c5")
+    assert b.n_pairs == 1000 and int(b.read_len.max()) > 9000 and int(b.hap_len.max()) > 11000
+    raw, l10, st = engine.compute(b)
+    assert not np.isnan(l10).any() and (np.isfinite(l10) | (l10 == -np.inf)).all()
+    assert (l10[np.isfinite(l10)] < 0).all()
+    assert int(st.cells) == b.cells()
+    perm = np.random.default_rng(5).permutation(b.n_pairs)
+    praw, pl10, _ = engine.compute(b.subset(perm))
+    assert np.array_equal(praw.view(np.uint32), raw[perm].view(np.uint32)) and np.array_equal(pl10, l10[perm])
+    monkeypatch.setenv("PHMM_NO_EARLY_EXIT", "1")
+    sub = np.arange(0, b.n_pairs, 4)  # the unshortened sweep is several times slower: a quarter of the pairs
+    nraw, nl10, _ = engine.compute(b.subset(sub))
+    assert np.array_equal(nraw.view(np.uint32), raw[sub].view(np.uint32)) and np.array_equal(nl10, l10[sub])
