@@ -91,53 +91,7 @@ struct swhip_context
     HostBytes stage, back, back_cigars;
 };
 
-extern "C" {
-
-int swhip_abi_version(void) { return SWHIP_ABI_VERSION; }
-const char *swhip_last_error(void) { return g_err; }
-
-int swhip_create(int device_id, void *stream, swhip_context **out)
-{
-    if (!out || device_id < 0) return fail(SWHIP_E_INVALID, "swhip_create: bad arguments");
-    *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-        return fail(SWHIP_E_NO_DEVICE, "swhip_create: no HIP device visible (this aligner has no CPU fallback)");
-    if (device_id >= n) return fail(SWHIP_E_NO_DEVICE, "swhip_create: device %d of %d does not exist", device_id, n);
-    HIP_TRY(hipSetDevice(device_id));
-    swhip_context *c = new (std::nothrow) swhip_context();
-    if (!c) return fail(SWHIP_E_NOMEM, "swhip_create: out of host memory");
-    c->device = device_id;
-    hipError_t e = hipSuccess;
-    if (stream) {
-        c->stream = static_cast<hipStream_t>(stream);
-    }
-    else {
-        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        c->own_stream = e == hipSuccess;
-    }
-    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e != hipSuccess) {
-        swhip_destroy(c);
-        return fail(SWHIP_E_HIP, "swhip_create: %s", hipGetErrorString(e));
-    }
-    *out = c;
-    return SWHIP_OK;
-}
-
-void swhip_destroy(swhip_context *c)
-{
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
-}
-
-int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch *b, swhip_alignment *out, uint32_t *cigars,
+static int swhip_align_impl(swhip_context *c, const swhip_params *params, const swhip_batch *b, swhip_alignment *out, uint32_t *cigars,
                 uint64_t cigar_capacity, uint64_t *cigars_used, swhip_stats *stats)
 {
     if (!c || !params || !b || (b->n_pairs && (!out || !cigars_used)))
@@ -152,7 +106,9 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
         return fail(SWHIP_E_INVALID, "swhip_align: null table pointer");
     // the kernel keeps scores in 31 bits around a bias (sw_device.h): penalties of the reference are below 300
     for (int32_t w : {params->match, params->mismatch, params->gap_open, params->gap_extend})
-        if (w > 65536 || w < -65536) return fail(SWHIP_E_INVALID, "swhip_align: scoring parameter %d outside [-65536, 65536]", w);
+        // the kernel drops sw_avx.c's MATRIX_MIN_CUTOFF clamp and keeps scores biased; that is bit-exact for |penalty| <= 512 on
+        // sequences under 2048 bases (sw_device.h), which covers both parameter sets of the reference (sw_avx.c:13-14)
+        if (w > 512 || w < -512) return fail(SWHIP_E_INVALID, "swhip_align: scoring parameter %d outside [-512, 512]", w);
     HIP_TRY(hipSetDevice(c->device));
 
     // ---- validate, find extents ----
@@ -337,6 +293,74 @@ int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch 
     }
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SWHIP_OK;
+}
+
+extern "C" {
+
+int swhip_abi_version(void) { return SWHIP_ABI_VERSION; }
+
+int swhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+const char *swhip_last_error(void) { return g_err; }
+
+int swhip_create(int device_id, void *stream, swhip_context **out)
+{
+    if (!out || device_id < 0) return fail(SWHIP_E_INVALID, "swhip_create: bad arguments");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SWHIP_E_NO_DEVICE, "swhip_create: no HIP device visible (this aligner has no CPU fallback)");
+    if (device_id >= n) return fail(SWHIP_E_NO_DEVICE, "swhip_create: device %d of %d does not exist", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    swhip_context *c = new (std::nothrow) swhip_context();
+    if (!c) return fail(SWHIP_E_NOMEM, "swhip_create: out of host memory");
+    c->device = device_id;
+    hipError_t e = hipSuccess;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    }
+    else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        c->own_stream = e == hipSuccess;
+    }
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        swhip_destroy(c);
+        return fail(SWHIP_E_HIP, "swhip_create: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return SWHIP_OK;
+}
+
+void swhip_destroy(swhip_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int swhip_align(swhip_context *c, const swhip_params *params, const swhip_batch *b, swhip_alignment *out, uint32_t *cigars,
+                uint64_t cigar_capacity, uint64_t *cigars_used, swhip_stats *stats)
+{
+    // nothing is thrown across the C boundary: a vector or a thread that cannot be had becomes SWHIP_E_NOMEM
+    try {
+        return swhip_align_impl(c, params, b, out, cigars, cigar_capacity, cigars_used, stats);
+    }
+    catch (const std::bad_alloc &) {
+        return fail(SWHIP_E_NOMEM, "swhip_align: out of host memory");
+    }
+    catch (...) {
+        return fail(SWHIP_E_NOMEM, "swhip_align: unexpected exception");
+    }
 }
 
 }  // extern "C"

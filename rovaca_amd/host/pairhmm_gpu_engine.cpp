@@ -81,9 +81,10 @@ struct RegionJob
     size_t read_bytes, hap_bytes;
     int32_t min_q, pcr_model;
     double *out;  // [read][hap]
-    // completion: `status` is written before `done` is released
+    // completion: `status` (and `error`, when it is a failure) are written before `done` is released
     std::atomic<bool> done{false};
     int status = PHMM_OK;
+    char error[256] = "";  // phmm_last_error() is thread-local to the dispatcher: the text travels with the job
 };
 
 // How long a thread polls before it sleeps on a condition variable (ROVACA_AMD_PAIRHMM_SPIN_US, default 0 = never).
@@ -236,6 +237,7 @@ private:
                 b.prep = &prep;
                 out.resize(pr.size());
                 const int rc = phmm_compute(ctx, &b, nullptr, out.data(), nullptr);
+                const char *why = rc == PHMM_OK ? "" : phmm_last_error();
                 regions += jobs.size();
                 submissions += 1;
                 size_t at = 0;
@@ -244,6 +246,7 @@ private:
                     if (rc == PHMM_OK) memcpy(j->out, out.data() + at, n * sizeof(double));
                     at += n;
                     j->status = rc;
+                    if (rc != PHMM_OK) snprintf(j->error, sizeof(j->error), "%s", why);
                     j->done.store(true, std::memory_order_release);  // the job may be gone from here on
                 }
                 bool wake;
@@ -364,11 +367,13 @@ DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32
     std::vector<double> likelihood_array(reads_num * haplotypes_num);  // [read][hap]
     const int model = static_cast<int>(pcr_option);
     int rc;
+    char why[256] = "";
     if (g_batching.load() && !g_batchers.empty()) {
         RegionJob job{bases.data(), quals.data(), mapq.data(), hap_bases.data(), read_off.data(), read_len.data(),
                       hap_off.data(), hap_len.data(), (uint32_t)reads_num, (uint32_t)haplotypes_num, total, hap_total,
                       min_quality_threshold, model, likelihood_array.data()};
         rc = g_batchers[g_next_batcher.fetch_add(1) % g_batchers.size()]->submit_and_wait(job);
+        if (rc != PHMM_OK) snprintf(why, sizeof(why), "%s", job.error);
     }
     else {
         phmm_read_prep prep{mapq.data(), min_quality_threshold, model, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
@@ -385,9 +390,10 @@ DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32
         b.hap_len = hap_len.data();
         b.prep = &prep;
         rc = phmm_compute(t_ctx.get(), &b, nullptr, likelihood_array.data(), nullptr);
+        if (rc != PHMM_OK) snprintf(why, sizeof(why), "%s", phmm_last_error());
     }
     if (rc != PHMM_OK) {
-        fprintf(stderr, "[rovaca_amd] pairhmm: device evaluation failed: %s\n", phmm_last_error());
+        fprintf(stderr, "[rovaca_amd] pairhmm: device evaluation failed (status %d): %s\n", rc, why);
         exit(EXIT_FAILURE);
     }
 

@@ -15,18 +15,30 @@
 #include <memory_resource>
 #include <vector>
 
+#ifdef ROVACA_AMD_WITH_REFERENCE_ENUM_AND_STRUCT
+// Partial in-tree build (tests/test_capi_cpu.py): the two boost-free headers of the reference replace the mirror's enum and
+// Bases, so that a drift between the mirror and the reference is a compile error here, not a link error in Rovaca.
+#include "common/enum.h"
+#include "genotype/genotype_struct.h"
+#else
+// GLOBAL namespace, as in the reference (common/enum.h:8): the enum is part of the seam's mangled signature.
+enum class PcrIndelModel : uint8_t { NONE = 0, HOSTILE, AGGRESSIVE, CONSERVATIVE };
+#endif
+
 namespace rovaca
 {
 
-enum class PcrIndelModel : uint8_t { NONE = 0, HOSTILE, AGGRESSIVE, CONSERVATIVE };  // common/enum.h:8
-
 typedef std::pmr::memory_resource MemoryPool, *pMemoryPool;
 
+#ifndef ROVACA_AMD_WITH_REFERENCE_ENUM_AND_STRUCT
 typedef struct Bases  // genotype/genotype_struct.h:11-15
 {
     uint32_t num;
     uint8_t data[];
 } Bases, *pBases;
+#else
+typedef struct Bases Bases, *pBases;  // genotype/forward.h:24
+#endif
 
 // genotype/genotype_macors.h:36
 #define ALLOC_FLEXIBLE_IN_POOL(pool, type1, num, type2) (pool->allocate(sizeof(type1) + sizeof(type2) * (num + 1)))

@@ -15,8 +15,24 @@
 
 #include "../../include/smithwaterman_hip.h"
 
+#include <algorithm>
+
 namespace
 {
+
+// device of the contexts created from here on: a fixed one, or (negative, the default) round-robin over the visible
+// devices per creating thread -- the rule of the PairHMM adapter (init_pairhmm_ptr_gpu), so that both engines of a run land
+// on the same GPUs
+std::atomic<int> g_sw_device{-1};
+std::atomic<uint32_t> g_sw_next_device{0};
+
+int pick_device()
+{
+    const int fixed = g_sw_device.load();
+    if (fixed >= 0) return fixed;
+    const int n = swhip_device_count();
+    return n > 0 ? (int)(g_sw_next_device.fetch_add(1) % (uint32_t)n) : 0;
+}
 
 struct ThreadContext
 {
@@ -27,7 +43,7 @@ struct ThreadContext
     }
     swhip_context *get()
     {
-        if (!ctx && swhip_create(0, nullptr, &ctx) != SWHIP_OK) {
+        if (!ctx && swhip_create(pick_device(), nullptr, &ctx) != SWHIP_OK) {
             fprintf(stderr, "[rovaca_amd] smith-waterman: cannot create a device context: %s\n", swhip_last_error());
             exit(EXIT_FAILURE);  // as the reference does on an unusable engine (pairhmm_engine.cpp:32-35)
         }
@@ -190,7 +206,9 @@ void start_batchers()
     const char *nd = getenv("ROVACA_AMD_SW_DISPATCHERS");
     int n = nd ? atoi(nd) : 1;  // one: a batch of up to ~2 000 alignments takes as long as one of 48 (lone waves), so merging wins
     n = n < 1 ? 1 : n > 16 ? 16 : n;
-    for (int i = 0; i < n; ++i) g_sw_batchers.push_back(new SwBatcher());
+    // with round-robin devices every device gets its dispatchers (a dispatcher's context is created on its own thread)
+    const int devices = g_sw_device.load() < 0 ? std::max(1, swhip_device_count()) : 1;
+    for (int i = 0; i < n * devices; ++i) g_sw_batchers.push_back(new SwBatcher());
 }
 
 }  // namespace
@@ -237,17 +255,22 @@ void sw_hip_run(p_lib_sw_avx p)
     p->max_i = out[0].max_i;
     p->max_j = out[0].max_j;
     p->alignment_offset = out[0].alignment_offset;
+    // sw_avx.c:349-358 keeps an element only while cur_size + 1 < cigar_max_len: at most cigar_max_len - 1 of them
     uint32_t count = (uint32_t)out[0].cigar.size();
-    if (count > p->cigar_max_len) count = p->cigar_max_len;
+    const uint32_t keep = p->cigar_max_len > 0 ? p->cigar_max_len - 1 : 0;
+    if (count > keep) count = keep;
     memcpy(p->cigar, out[0].cigar.data(), count * sizeof(uint32_t));
     p->cigar_count = count;
 }
+
+void sw_hip_set_device(int device_id) { g_sw_device.store(device_id); }
 
 int sw_hip_install(p_lib_sw_avx p)
 {
     if (!p) return 0;
     swhip_context *probe = nullptr;
-    if (swhip_create(0, nullptr, &probe) != SWHIP_OK) return 0;  // no device: the AVX selection stays
+    const int dev = g_sw_device.load() >= 0 ? g_sw_device.load() : 0;
+    if (swhip_create(dev, nullptr, &probe) != SWHIP_OK) return 0;  // no device: the AVX selection stays
     swhip_destroy(probe);
     p->avx_function = sw_hip_run;
     return 1;

@@ -33,6 +33,11 @@ void sw_hip_run(p_lib_sw_avx p);
 // otherwise (the AVX selection of sw_avx_init stays in force; there is no CPU path in this library).
 int sw_hip_install(p_lib_sw_avx p);
 
+// Device of the contexts this adapter creates from now on: >= 0 pins it (pass what init_pairhmm_ptr_gpu was given), negative
+// (the default) spreads creating threads round-robin over the visible devices, like the PairHMM adapter.  Call before the
+// first alignment.
+void sw_hip_set_device(int device_id);
+
 #ifdef __cplusplus
 }
 

@@ -55,7 +55,7 @@ def test_sw_library_exports_every_declared_symbol_and_refuses_without_device():
     text = open(os.path.join(ROOT, "include", "smithwaterman_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = sorted(set(re.findall(r"\b(swhip_[a-z0-9_]+)\s*\(", text)))
-    assert names == ["swhip_abi_version", "swhip_align", "swhip_create", "swhip_destroy", "swhip_last_error"]
+    assert names == ["swhip_abi_version", "swhip_align", "swhip_create", "swhip_destroy", "swhip_device_count", "swhip_last_error"]
     L = swapi.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/smithwaterman_hip.h but not exported"
@@ -103,3 +103,45 @@ def test_sw_adapter_compiles_against_the_reference_header():
                "-o", os.path.join(d, "sw_intree.o")]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_pairhmm_seam_mirror_against_the_reference_headers():
+    # rovaca_amd/host/rovaca_seam.h restates the few Rovaca types the seam touches.  genotype/forward.h needs boost (absent
+    # here), but common/enum.h and genotype/genotype_struct.h do not: build the check TU and the adapter itself with the
+    # reference's own two headers swapped in, and compare the mangled seam signature of both builds.
+    import shutil
+    import subprocess
+    import tempfile
+    ref = "/root/reference/src/haplotypecaller"
+    host = os.path.join(ROOT, "rovaca_amd", "host")
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    have_ref = os.path.exists(os.path.join(ref, "common", "enum.h"))
+    with tempfile.TemporaryDirectory() as d:
+        names, symbols = [], []
+        for tag, extra in (("mirror", []), ("reference", ["-DROVACA_AMD_WITH_REFERENCE_ENUM_AND_STRUCT", "-I" + ref])):
+            if tag == "reference" and not have_ref:
+                continue
+            exe = os.path.join(d, "seam_" + tag)
+            r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + host, *extra,
+                                os.path.join(ROOT, "tests", "seam_check.cpp"), "-o", exe], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            names.append(subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip())
+            obj = os.path.join(d, "engine_" + tag + ".o")
+            r = subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-Wall", "-Wextra", "-Werror", "-I" + host,
+                                "-I" + os.path.join(ROOT, "include"), *extra, "-c", os.path.join(host, "pairhmm_gpu_engine.cpp"),
+                                "-o", obj], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            nm = subprocess.run(["nm", "--defined-only", obj], capture_output=True, text=True, check=True).stdout
+            symbols.append(sorted(l.split()[-1] for l in nm.splitlines() if "call_gpu_pairhmm" in l and " T " in l))
+        # PcrIndelModel is mangled as a GLOBAL enum (13PcrIndelModel, not N6rovaca13PcrIndelModelE)
+        assert all("13PcrIndelModel" in n and "6rovaca13PcrIndelModel" not in n for n in names), names
+        assert all(len(s) == 1 for s in symbols), symbols
+        assert symbols[0][0] == ("_ZN6rovaca16call_gpu_pairhmmERKSt6vectorIPNS_9HaplotypeENSt3pmr21polymorphic_allocatorIS2_EEERS0_IPNS_10ReadRecordE"
+                                 "NS4_ISA_EEEi13PcrIndelModelPNS3_15memory_resourceE")
+        if have_ref:
+            assert names[0] == names[1] and symbols[0] == symbols[1]
+        # the shipped stand-alone library exports exactly that symbol
+        nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "rovaca_amd", "lib", "librovaca_pairhmm_host.so")],
+                            capture_output=True, text=True, check=True).stdout
+        assert symbols[0][0] in nm
