@@ -57,6 +57,7 @@ int phmm_compute(phmm_context *, const phmm_batch *b, float *, double *out_log10
     return PHMM_OK;
 }
 int swhip_abi_version(void) { return SWHIP_ABI_VERSION; }
+int swhip_device_count(void) { return 1; }
 const char *swhip_last_error(void) { return ""; }
 int swhip_create(int, void *, swhip_context **out)
 {
