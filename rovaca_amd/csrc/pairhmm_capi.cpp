@@ -132,6 +132,10 @@ struct phmm_context
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
     struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
+    // big one-shot batches are cut into chunks that alternate between two resident slots: chunk k + 1 is binned, packed and
+    // uploaded (on side[2]) while chunk k is swept, chunk k - 1 finalised on the host meanwhile
+    struct phmm_resident *chunk_slot[2] = {nullptr, nullptr};
+    hipEvent_t chunk_up[2] = {nullptr, nullptr}, chunk_done[2] = {nullptr, nullptr};
     std::vector<uint32_t> bin_hist, bin_slot;  // host scratch of the length binning, kept between calls
     std::vector<hipEvent_t> timing;            // event pool of phmm_sweep_timed
 };
@@ -226,7 +230,7 @@ struct phmm_resident
 
 // Host loops over the pairs of a BIG batch (binning, the final log10) are split over a few threads; a region-sized call
 // never gets here.
-constexpr uint64_t kParallelMinPairs = 1u << 18;
+constexpr uint64_t kParallelMinPairs = 1u << 17;
 template <typename F>
 static void parallel_ranges(uint64_t n, unsigned n_threads, F &&fn)  // fn(lo, hi, thread index)
 {
@@ -338,6 +342,11 @@ void phmm_destroy(phmm_context *c)
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
     }
     delete c->scratch;
+    for (int i = 0; i < 2; ++i) {
+        delete c->chunk_slot[i];
+        if (c->chunk_up[i]) (void)hipEventDestroy(c->chunk_up[i]);
+        if (c->chunk_done[i]) (void)hipEventDestroy(c->chunk_done[i]);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -376,7 +385,17 @@ struct PhaseClock
 static thread_local PhaseClock *g_phase = nullptr;
 #define PHASE(i) do { if (g_phase) g_phase->lap(i); } while (0)
 
-static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
+// How a batch reaches the device.  The defaults are the plain upload; the chunked one-shot call (phmm_compute on a big batch)
+// uploads on a side stream without waiting for the context's stream, and hands in windows of the tables with the pair
+// indices still counted from the start of the caller's tables.
+struct UploadOpts
+{
+    hipStream_t stream = nullptr;  // null: the context's stream
+    bool caller_synchronised = false;  // the caller knows that nothing on the device still reads this resident's buffers
+    uint32_t read_bias = 0, hap_bias = 0;  // subtracted from pair_read / pair_hap
+};
+
+static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt = UploadOpts())
 {
     if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
         return fail(PHMM_E_INVALID, "phmm_upload: pair_read and pair_hap must both be given or both be NULL");
@@ -424,26 +443,35 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     // the Rovaca case -- one gap-continuation penalty for every base and deletion gap-open == insertion gap-open
     // (read_record.cpp:205-210, pairhmm_internal.cpp:425) -- selects the kernel variant that shares those constants
     bool ug = read_bytes > 0;
-    if (!prep) {
-        const uint8_t c0 = read_bytes ? (b->read_gcp[b->read_off[0]] & 127) : 0;
+    uint8_t gcp0 = 0;
+    if (!prep && read_bytes) {
+        gcp0 = b->read_gcp[b->read_off[0]] & 127;
+        const bool same_array = b->read_del == b->read_ins;
         for (uint32_t r = 0; r < b->n_reads && ug; ++r) {
             const uint8_t *g = b->read_gcp + b->read_off[r];
             const uint8_t *gi = b->read_ins + b->read_off[r], *gd = b->read_del + b->read_off[r];
-            for (uint32_t i = 0; i < b->read_len[r]; ++i)
-                if ((g[i] & 127) != c0 || ((gi[i] ^ gd[i]) & 127)) {
-                    ug = false;
-                    break;
-                }
+            const uint32_t n = b->read_len[r];
+            uint8_t diff = 0;  // OR of every deviation: no early exit inside a read, so the loop vectorises
+            if (same_array)
+                for (uint32_t i = 0; i < n; ++i) diff |= (uint8_t)(g[i] ^ gcp0);
+            else
+                for (uint32_t i = 0; i < n; ++i) diff |= (uint8_t)((g[i] ^ gcp0) | (gi[i] ^ gd[i]));
+            ug = (diff & 127) == 0;
         }
     }
     rb->uniform_gcp = ug;
+    // In the Rovaca case two of the five read arrays carry no information: the deletion gap-opens are the insertion ones and
+    // the gap-continuation array is one value.  They are not packed or copied: on the device `del` aliases `ins` and `gcp` is
+    // a fill (a big one-shot batch spends more host time packing tables than binning pairs).
+    const bool slim = ug && !prep;
 
     // ---- stage layout: every input travels in ONE pinned buffer and ONE copy; the index arrays are built in place ----
     uint64_t slots = 0;
     for (uint32_t h = 0; h < b->n_haps; ++h) slots += phmm::planes_words(b->hap_len[h]);
     if (slots * phmm::kPlanes > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_upload: haplotype table too large");
-    hipStream_t st = c->stream;
-    HIP_TRY(hipStreamSynchronize(st));  // the previous pass of this resident batch no longer reads the stage or the blob
+    hipStream_t st = opt.stream ? opt.stream : c->stream;
+    if (!opt.caller_synchronised)
+        HIP_TRY(hipStreamSynchronize(c->stream));  // the previous pass of this resident batch no longer reads the stage or the blob
     size_t total = 0;
     auto reserve = [&](size_t bytes) {
         const size_t at = total;
@@ -452,7 +480,8 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     };
     const size_t o_bases = reserve(read_bytes), o_qual = reserve(read_bytes);
     const size_t o_mapq = reserve(prep ? b->n_reads : 0);
-    const size_t o_ins = reserve(prep ? 0 : read_bytes), o_del = reserve(prep ? 0 : read_bytes), o_gcp = reserve(prep ? 0 : read_bytes);
+    const size_t o_ins = reserve(prep ? 0 : read_bytes), o_del = reserve(prep || slim ? 0 : read_bytes),
+                 o_gcp = reserve(prep || slim ? 0 : read_bytes);
     const size_t o_roff = reserve(b->n_reads * sizeof(uint32_t)), o_rlen = reserve(b->n_reads * sizeof(uint32_t));
     const size_t o_hap = reserve(hap_bytes);
     const size_t o_hoff = reserve(b->n_haps * sizeof(uint32_t)), o_hlen = reserve(b->n_haps * sizeof(uint32_t));
@@ -463,7 +492,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     HIP_TRY(rb->blob.alloc(total));
     uint8_t *stage = static_cast<uint8_t *>(rb->stage.p);
     auto copy = [](void *dst, const void *src, size_t bytes) {  // big tables of a big batch: a few threads share the copy
-        if (bytes < (size_t(4) << 20)) {
+        if (bytes < (size_t(1) << 20)) {
             memcpy(dst, src, bytes);
             return;
         }
@@ -478,8 +507,10 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     if (prep && b->n_reads) copy(stage + o_mapq, prep->read_mapq, b->n_reads);
     if (!prep && read_bytes) {
         copy(stage + o_ins, b->read_ins, read_bytes);
-        copy(stage + o_del, b->read_del, read_bytes);
-        copy(stage + o_gcp, b->read_gcp, read_bytes);
+        if (!slim) {
+            copy(stage + o_del, b->read_del, read_bytes);
+            copy(stage + o_gcp, b->read_gcp, read_bytes);
+        }
     }
     if (b->n_reads) {
         copy(stage + o_roff, b->read_off, b->n_reads * sizeof(uint32_t));
@@ -562,8 +593,8 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
                     h = (uint32_t)(p % b->n_haps);
                 }
                 else {
-                    r = b->pair_read[p];
-                    h = b->pair_hap[p];
+                    r = b->pair_read[p] - opt.read_bias;  // (an index below the bias wraps and fails the range check)
+                    h = b->pair_hap[p] - opt.hap_bias;
                     if (r >= b->n_reads || h >= b->n_haps) {
                         uint64_t expect = UINT64_MAX;
                         bad_pair.compare_exchange_strong(expect, p);
@@ -648,8 +679,8 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
                 h = (uint32_t)(p % b->n_haps);
             }
             else {
-                r = b->pair_read[p];
-                h = b->pair_hap[p];
+                r = b->pair_read[p] - opt.read_bias;
+                h = b->pair_hap[p] - opt.hap_bias;
                 if (r >= b->n_reads || h >= b->n_haps)
                     return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)p);
             }
@@ -703,8 +734,16 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb)
     }
     else {
         rb->read_ins = {base + o_ins, (size_t)read_bytes};
-        rb->read_del = {base + o_del, (size_t)read_bytes};
-        rb->read_gcp = {base + o_gcp, (size_t)read_bytes};
+        if (slim) {
+            HIP_TRY(rb->prep_gcp.alloc(read_bytes));
+            HIP_TRY(hipMemsetAsync(rb->prep_gcp.p, gcp0, read_bytes, st));
+            rb->read_del = rb->read_ins;  // pairhmm_internal.cpp:425 does the same on the host
+            rb->read_gcp = {rb->prep_gcp.p, (size_t)read_bytes};
+        }
+        else {
+            rb->read_del = {base + o_del, (size_t)read_bytes};
+            rb->read_gcp = {base + o_gcp, (size_t)read_bytes};
+        }
     }
     HIP_TRY(rb->planes.alloc(slots * phmm::kPlanes));
     // the rescue count lives behind the fp32 sums so that both come back in one copy
@@ -1076,10 +1115,277 @@ int phmm_download_read_table(phmm_context *c, phmm_resident *rb, uint8_t *qual, 
     return PHMM_OK;
 }
 
+// ---- the chunked one-shot call ----
+// A window of the caller's tables that holds everything a contiguous range of the pair list refers to.
+struct ChunkWindow
+{
+    uint64_t p0 = 0, p1 = 0;               // pairs
+    uint32_t r0 = 0, r1 = 0, h0 = 0, h1 = 0;  // reads [r0, r1), haplotypes [h0, h1)
+    uint64_t rb0 = 0, rb1 = 0, hb0 = 0, hb1 = 0;  // byte ranges of the two tables
+};
+
+constexpr uint64_t kChunkedMinPairs = 1u << 19;  // below this one upload + one sweep is as fast
+constexpr uint64_t kChunkTargetPairs = 1u << 18;
+constexpr unsigned kMaxChunks = 8;
+
+// Cuts the pair list into contiguous chunks and finds each chunk's table windows.  Returns false when chunking would not
+// pay: a small batch, or a pair list that jumps around the tables so that the windows overlap heavily (each chunk would
+// upload most of the tables again).
+static bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
+{
+    const bool cross = b->pair_read == nullptr;
+    const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
+    if (n < kChunkedMinPairs || b->n_reads == 0 || b->n_haps == 0) return false;
+    if (const char *e = getenv("PHMM_NO_CHUNKED_COMPUTE")) {  // tests
+        if (e[0] != '0') return false;
+    }
+    // Chunk sizes rise and fall (1 : 2 : 3 : 3 : 2 : 1): the first chunk's packing and the last chunk's host log10 are the
+    // only host work the device cannot hide, so those two chunks are the small ones.
+    const unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(2, n / kChunkTargetPairs + 2));
+    std::vector<uint64_t> cut(C + 1, 0);
+    {
+        uint64_t wsum = 0, run = 0;
+        for (unsigned k = 0; k < C; ++k) wsum += std::min(k + 1, std::min(C - k, 3u));
+        for (unsigned k = 0; k < C; ++k) {
+            run += std::min(k + 1, std::min(C - k, 3u));
+            cut[k + 1] = cross ? (uint64_t)b->n_reads * run / wsum : n * run / wsum;
+        }
+    }
+    plan.assign(C, ChunkWindow());
+    std::atomic<bool> bad{false};
+    parallel_ranges(C, std::min(C, host_threads()), [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t k = lo; k < hi; ++k) {
+            ChunkWindow &w = plan[k];
+            if (cross) {
+                w.r0 = (uint32_t)cut[k];
+                w.r1 = (uint32_t)cut[k + 1];
+                w.p0 = (uint64_t)w.r0 * b->n_haps;
+                w.p1 = (uint64_t)w.r1 * b->n_haps;
+                w.h0 = 0;
+                w.h1 = b->n_haps;
+            }
+            else {
+                w.p0 = cut[k];
+                w.p1 = cut[k + 1];
+                uint32_t rmin = UINT32_MAX, rmax = 0, hmin = UINT32_MAX, hmax = 0;
+                for (uint64_t p = w.p0; p < w.p1; ++p) {
+                    const uint32_t r = b->pair_read[p], h = b->pair_hap[p];
+                    rmin = std::min(rmin, r);
+                    rmax = std::max(rmax, r);
+                    hmin = std::min(hmin, h);
+                    hmax = std::max(hmax, h);
+                }
+                if (w.p1 == w.p0 || rmax >= b->n_reads || hmax >= b->n_haps) {
+                    bad.store(true);  // empty chunk or an index out of range: let the plain path report it
+                    return;
+                }
+                w.r0 = rmin;
+                w.r1 = rmax + 1;
+                w.h0 = hmin;
+                w.h1 = hmax + 1;
+            }
+            uint64_t lo_b = UINT64_MAX, hi_b = 0;
+            for (uint32_t r = w.r0; r < w.r1; ++r) {
+                lo_b = std::min<uint64_t>(lo_b, b->read_off[r]);
+                hi_b = std::max<uint64_t>(hi_b, (uint64_t)b->read_off[r] + b->read_len[r]);
+            }
+            w.rb0 = w.r1 > w.r0 ? lo_b : 0;
+            w.rb1 = w.r1 > w.r0 ? hi_b : 0;
+            lo_b = UINT64_MAX;
+            hi_b = 0;
+            for (uint32_t h = w.h0; h < w.h1; ++h) {
+                lo_b = std::min<uint64_t>(lo_b, b->hap_off[h]);
+                hi_b = std::max<uint64_t>(hi_b, (uint64_t)b->hap_off[h] + b->hap_len[h]);
+            }
+            w.hb0 = w.h1 > w.h0 ? lo_b : 0;
+            w.hb1 = w.h1 > w.h0 ? hi_b : 0;
+        }
+    });
+    if (bad.load()) return false;
+    uint64_t win_bytes = 0, all_lo = UINT64_MAX, all_hi = 0, hall_lo = UINT64_MAX, hall_hi = 0;
+    for (const ChunkWindow &w : plan) {
+        if (w.p1 == w.p0) return false;
+        win_bytes += 5 * (w.rb1 - w.rb0) + (w.hb1 - w.hb0);
+        all_lo = std::min(all_lo, w.rb0);
+        all_hi = std::max(all_hi, w.rb1);
+        hall_lo = std::min(hall_lo, w.hb0);
+        hall_hi = std::max(hall_hi, w.hb1);
+    }
+    const uint64_t once = 5 * (all_hi - all_lo) + (hall_hi - hall_lo);
+    return win_bytes <= once + once / 2 + (1u << 20);
+}
+
+static int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<ChunkWindow> &plan, float *out_raw_f32,
+                           double *out_log10, phmm_stats *stats)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < 2; ++i) {
+        if (!c->chunk_slot[i]) {
+            c->chunk_slot[i] = new (std::nothrow) phmm_resident();
+            if (!c->chunk_slot[i]) return fail(PHMM_E_NOMEM, "phmm_compute: out of host memory");
+        }
+        if (!c->chunk_up[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_up[i], hipEventDisableTiming));
+        if (!c->chunk_done[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming));
+    }
+    hipStream_t up = c->side[phmm_context::kSideStreams - 1];  // not used by the sweeps (n_side defaults to 2 of 3)
+    const bool sweeps_use_it = c->n_side >= phmm_context::kSideStreams;
+    if (sweeps_use_it) up = c->stream;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // nothing of an earlier call still reads the slots
+    if (up != c->stream) HIP_TRY(hipStreamSynchronize(up));
+    const bool cross = b->pair_read == nullptr;
+    phmm_stats total{};
+    std::vector<uint32_t> roff, hoff;
+    struct InFlight
+    {
+        const ChunkWindow *w = nullptr;
+        size_t count_at = 0;
+    } fl[2];
+
+    // results of chunk `slot` (its sums and rescue counts are on their way to the slot's pinned staging): wait, fetch the
+    // fp64 sums if anything was rescued, finalise on the host (pairhmm_internal.cpp:577-585)
+    auto collect = [&](int slot) -> int {
+        phmm_resident *rb = c->chunk_slot[slot];
+        const ChunkWindow &w = *fl[slot].w;
+        const uint64_t n = rb->n_pairs;
+        HIP_TRY(hipEventSynchronize(c->chunk_done[slot]));
+        const size_t off_cnt = fl[slot].count_at * sizeof(float), off64 = off_cnt + 256;
+        const uint8_t *st = static_cast<const uint8_t *>(rb->out_stage.p);
+        const uint32_t *counts = reinterpret_cast<const uint32_t *>(st + off_cnt);
+        rb->last_rescued = 0;
+        for (int qi = 0; qi < kQueues; ++qi) rb->last_rescued += counts[qi];
+        const bool want64 = out_log10 && rb->last_rescued;
+        if (want64) {
+            // the rescue kernels of this chunk are done (the event above follows them); the copy runs beside the next sweep
+            HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(st) + off64, rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, up));
+            HIP_TRY(hipStreamSynchronize(up));
+        }
+        const float *rp = reinterpret_cast<const float *>(st);
+        const double *r64 = reinterpret_cast<const double *>(st + off64);
+        if (out_raw_f32) memcpy(out_raw_f32 + w.p0, rp, n * sizeof(float));
+        if (out_log10) {
+            double *dst = out_log10 + w.p0;
+            auto finalize = [&](uint64_t lo, uint64_t hi, unsigned) {
+                for (uint64_t p = lo; p < hi; ++p) {
+                    const float x = rp[p];
+                    if (x < PHMM_MIN_ACCEPTED_F32)
+                        dst[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
+                    else
+                        dst[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
+                }
+            };
+            if (n >= kParallelMinPairs)
+                parallel_ranges(n, std::min(4u, host_threads()), finalize);
+            else
+                finalize(0, n, 0);
+        }
+        total.cells += rb->cells;
+        total.n_rescued += rb->last_rescued;
+        total.n_launches += (uint32_t)rb->bins.size();
+        if (!rb->bins.empty()) total.max_rows_per_lane = std::max<uint32_t>(total.max_rows_per_lane, (uint32_t)rb->bins.back().rows_per_lane);
+        return PHMM_OK;
+    };
+
+    const bool trace = getenv("PHMM_PHASE_TIMING") != nullptr;  // tuning aid: host time line of the pipeline on stderr
+    PhaseClock clock;
+    struct PhaseScope
+    {
+        explicit PhaseScope(PhaseClock *p) { g_phase = p; }
+        ~PhaseScope() { g_phase = nullptr; }
+    } phase_scope(trace ? &clock : nullptr);
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+    for (size_t k = 0; k < plan.size(); ++k) {
+        const ChunkWindow &w = plan[k];
+        const int slot = (int)(k & 1);
+        const double t_a = trace ? now_us() : 0.0;
+        phmm_resident *rb = c->chunk_slot[slot];
+        // the chunk as a batch of its own: windows of the tables, offsets rebased to the windows, pair indices biased
+        phmm_batch s = *b;
+        s.n_reads = w.r1 - w.r0;
+        s.n_haps = w.h1 - w.h0;
+        s.n_pairs = w.p1 - w.p0;
+        roff.resize(s.n_reads);
+        for (uint32_t r = 0; r < s.n_reads; ++r) roff[r] = (uint32_t)(b->read_off[w.r0 + r] - w.rb0);
+        hoff.resize(s.n_haps);
+        for (uint32_t h = 0; h < s.n_haps; ++h) hoff[h] = (uint32_t)(b->hap_off[w.h0 + h] - w.hb0);
+        s.read_bases = b->read_bases + w.rb0;
+        s.read_qual = b->read_qual + w.rb0;
+        s.read_ins = b->read_ins ? b->read_ins + w.rb0 : nullptr;
+        s.read_del = b->read_del ? b->read_del + w.rb0 : nullptr;
+        s.read_gcp = b->read_gcp ? b->read_gcp + w.rb0 : nullptr;
+        s.read_off = roff.data();
+        s.read_len = b->read_len + w.r0;
+        s.hap_bases = b->hap_bases + w.hb0;
+        s.hap_off = hoff.data();
+        s.hap_len = b->hap_len + w.h0;
+        s.pair_read = cross ? nullptr : b->pair_read + w.p0;
+        s.pair_hap = cross ? nullptr : b->pair_hap + w.p0;
+        phmm_read_prep prep_k;
+        if (b->prep) {
+            prep_k = *b->prep;
+            prep_k.read_mapq = b->prep->read_mapq ? b->prep->read_mapq + w.r0 : nullptr;
+            s.prep = &prep_k;
+        }
+        UploadOpts opt;
+        opt.stream = up;
+        opt.caller_synchronised = true;  // slot `slot` held chunk k - 2, collected during the last iteration
+        opt.read_bias = cross ? 0 : w.r0;
+        opt.hap_bias = cross ? 0 : w.h0;
+        int rc = upload_into(c, &s, rb, opt);
+        if (rc != PHMM_OK) return rc;
+        if (up != c->stream) {
+            HIP_TRY(hipEventRecord(c->chunk_up[slot], up));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->chunk_up[slot], 0));
+        }
+        if (k == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        rc = impl::phmm_sweep(c, rb);
+        if (rc != PHMM_OK) return rc;
+        if (k + 1 == plan.size()) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        const uint64_t n = rb->n_pairs;
+        const size_t count_at = (n + 63) & ~size_t(63);
+        HIP_TRY(rb->out_stage.ensure(count_at * sizeof(float) + 256 + n * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, count_at * sizeof(float) + kQueues * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->chunk_done[slot], c->stream));
+        fl[slot].w = &w;
+        fl[slot].count_at = count_at;
+        const double t_b = trace ? now_us() : 0.0;
+        if (k > 0) {
+            rc = collect((int)((k - 1) & 1));  // the GPU sweeps chunk k meanwhile
+            if (rc != PHMM_OK) return rc;
+        }
+        if (trace)
+            fprintf(stderr, "phmm chunk %zu: %llu pairs, pack+enqueue %.0f..%.0f us, previous chunk collected at %.0f us\n", k,
+                    (unsigned long long)(w.p1 - w.p0), t_a, t_b, now_us());
+    }
+    int rc = collect((int)((plan.size() - 1) & 1));
+    if (rc != PHMM_OK) return rc;
+    if (trace)
+        fprintf(stderr, "phmm chunked phases us (summed over chunks): validate %.1f pack %.1f bin %.1f enqueue-upload %.1f\n", clock.us[0],
+                clock.us[1], clock.us[2], clock.us[3]);
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        total.kernel_ms = ms;
+        *stats = total;
+    }
+    return PHMM_OK;
+}
+
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats)
 {
     if (!c || !b) return fail(PHMM_E_INVALID, "phmm_compute: null argument");
     const auto t0 = std::chrono::steady_clock::now();
+    {
+        std::vector<ChunkWindow> plan;
+        const bool tables_ok = b->read_bases && b->read_qual && b->read_off && b->read_len && b->hap_bases && b->hap_off && b->hap_len &&
+                               ((b->pair_read == nullptr) == (b->pair_hap == nullptr)) && (b->prep ? b->prep->read_mapq != nullptr : true);
+        if (tables_ok && plan_chunks(b, plan)) {
+            const int rc = compute_chunked(c, b, plan, out_raw_f32, out_log10, stats);
+            if (rc == PHMM_OK && stats)
+                stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return rc;
+        }
+    }
     if (!c->scratch) {
         c->scratch = new (std::nothrow) phmm_resident();
         if (!c->scratch) return fail(PHMM_E_NOMEM, "phmm_compute: out of host memory");

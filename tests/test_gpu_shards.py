@@ -219,3 +219,38 @@ def test_config5_full_size_properties(engine, monkeypatch):
     sub = np.arange(0, b.n_pairs, 4)  # the unshortened sweep is several times slower: a quarter of the pairs
     nraw, nl10, _ = engine.compute(b.subset(sub))
     assert np.array_equal(nraw.view(np.uint32), raw[sub].view(np.uint32)) and np.array_equal(nl10, l10[sub])
+
+
+def test_chunked_one_shot_compute_is_the_plain_one(engine, monkeypatch):
+    # phmm_compute cuts a big batch into chunks (binning, packing and upload of chunk k + 1 under the sweep of chunk k, host
+    # log10 of chunk k - 1 meanwhile): same bits as one upload + one sweep, for an explicit pair list, for the full cross
+    # product, with device-side read preparation, and for a pair list that jumps around the tables (no chunking then)
+    b = synth.make_batch(seed=52, n_regions=560, reads=40, haps=25, read_len=(60, 200), hap_len=(150, 400))
+    assert b.n_pairs >= 1 << 19
+    raw, l10, st = engine.compute(b)
+    assert int(st.cells) == b.cells()
+    monkeypatch.setenv("PHMM_NO_CHUNKED_COMPUTE", "1")
+    praw, pl10, pst = engine.compute(b)
+    monkeypatch.delenv("PHMM_NO_CHUNKED_COMPUTE")
+    assert np.array_equal(raw.view(np.uint32), praw.view(np.uint32)) and np.array_equal(l10, pl10, equal_nan=True)
+    assert int(st.n_rescued) == int(pst.n_rescued)
+    idx = np.sort(np.random.default_rng(1).choice(b.n_pairs, 4000, replace=False))
+    oraw, ol10, oresc = oracle.batch(b.subset(idx), n_threads=8)
+    assert np.array_equal(raw[idx].view(np.uint32), oraw.view(np.uint32)) and np.array_equal(l10[idx][~oresc], ol10[~oresc])
+    # shuffled pair list: every chunk would need the whole tables -> falls back to one upload; still the same numbers
+    perm = np.random.default_rng(2).permutation(b.n_pairs)
+    sraw, _, _ = engine.compute(b.subset(perm))
+    assert np.array_equal(sraw.view(np.uint32), raw[perm].view(np.uint32))
+    # full cross product of a read table and a haplotype table (pair arrays NULL): chunked over the reads
+    cross = synth.make_batch(seed=53, n_regions=1, reads=9000, haps=64, read_len=(50, 120), hap_len=200)
+    craw, cl10, _ = engine.compute(cross, cross=True)
+    monkeypatch.setenv("PHMM_NO_CHUNKED_COMPUTE", "1")
+    draw, dl10, _ = engine.compute(cross, cross=True)
+    monkeypatch.delenv("PHMM_NO_CHUNKED_COMPUTE")
+    assert cross.n_pairs >= 1 << 19 and np.array_equal(craw.view(np.uint32), draw.view(np.uint32)) and np.array_equal(cl10, dl10)
+    # device-side read preparation travels with the chunks (mapping qualities are windowed like the read table)
+    mapq = np.random.default_rng(3).choice(np.array([60, 29, 12], np.uint8), b.n_reads)
+    qraw, ql10, _ = engine.compute(b, prep=(mapq, 18, 3))
+    monkeypatch.setenv("PHMM_NO_CHUNKED_COMPUTE", "1")
+    rraw, rl10, _ = engine.compute(b, prep=(mapq, 18, 3))
+    assert np.array_equal(qraw.view(np.uint32), rraw.view(np.uint32)) and np.array_equal(ql10, rl10, equal_nan=True)
