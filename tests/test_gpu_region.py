@@ -103,3 +103,40 @@ def test_cross_region_batching_coalesces_concurrent_workers():
     assert r1 - r0 == 32 * 8
     assert s1 - s0 < r1 - r0, "no coalescing happened"
     print(f"256 regions from 32 workers in {dt*1e3:.1f} ms: {s1 - s0} device submissions")
+
+
+def test_device_side_preparation_against_the_hand_derived_answers():
+    # tests/golden/host_logic_known_answers.json: worked out on paper from pairhmm_internal.cpp (H3, H4).  The device-side
+    # read preparation (setup_kernel) must give exactly those bytes.
+    import json
+    import os
+    from rovaca_amd import capi
+    from rovaca_amd.batch import Batch
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_logic_known_answers.json")))
+    eng = capi.Engine(0)
+    hap = np.frombuffer(b"ACGTACGTAC", np.uint8)
+    for model in (0, 1, 2, 3):
+        cases = [c for c in fx["apply_pcr_error_model"] if c["model"] == model and isinstance(c["gop_in"], int)]
+        reads = []
+        for c in cases:
+            s = np.frombuffer(c["bases"].encode(), np.uint8)
+            z = np.zeros(len(s), np.uint8)
+            reads.append((s, np.full(len(s), 30, np.uint8), z, z, z))
+        b = Batch.from_lists(reads, [hap], [(k, 0) for k in range(len(reads))])
+        rb = eng.upload(b, prep=(np.full(len(reads), 60, np.uint8), 18, model, 45, 10))
+        q, ins, dele, gcp = rb.read_table()
+        rb.release()
+        want = np.concatenate([np.array(c["expect"], np.uint8) for c in cases])
+        assert np.array_equal(ins, want) and np.array_equal(dele, want), model
+        assert (gcp == 10).all() and (q == 30).all()
+    for c in fx["modify_read_qualities"]:
+        qual = np.array(c["qual"], np.uint8)
+        n = len(qual)
+        s = np.frombuffer(b"ACGTACGTAC"[:n].ljust(n, b"A"), np.uint8)
+        z = np.zeros(n, np.uint8)
+        b = Batch.from_lists([(s, qual, z, z, z)], [hap], [(0, 0)])
+        rb = eng.upload(b, prep=(np.array([c["mapq"]], np.uint8), c["threshold"], 0, 45, 10))
+        q, _, _, _ = rb.read_table()
+        rb.release()
+        assert q.tolist() == c["expect"], c["why"]
+    eng.close()

@@ -1,6 +1,7 @@
 """Host-side logic of the drop-in adapter (quality modification, PCR indel model, normalisation, read filter) against
 the oracle restatement and hand-derived known answers.  CPU only."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -123,3 +124,68 @@ def test_adapter_refuses_without_device():
     with pytest.raises(RuntimeError, match="not installed"):
         hostapi.call_region(np.frombuffer(b"ACGT", np.uint8), np.full(4, 30, np.uint8), [0], [4], [60],
                             np.frombuffer(b"ACGTA", np.uint8), [0], [5])
+
+
+# ---- hand-derived known answers (tests/golden/host_logic_known_answers.json): the only pin H3/H4/H8 can have ----
+def _fixture():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_logic_known_answers.json")))
+
+
+def _f(v):
+    return float(v) if isinstance(v, str) else v
+
+
+def test_known_answers_tandem_repeat_length():
+    H, O = hostapi.lib(), oracle.lib()
+    n_cases = 0
+    for case in _fixture()["tandem_repeat_length"]:
+        s = np.frombuffer(case["bases"].encode(), np.uint8).copy()
+        for off, want in zip(case["offsets"], case["expect"]):
+            assert H.rovaca_amd_tandem_repeat_length(s, len(s), off) == want, (case["bases"], off, case["why"])
+            assert O.phmm_oracle_find_tandem_repeat_units(s, len(s), off) == want, (case["bases"], off)
+            n_cases += 1
+    assert n_cases >= 60
+
+
+def test_known_answers_pcr_error_model():
+    H, O = hostapi.lib(), oracle.lib()
+    for case in _fixture()["apply_pcr_error_model"]:
+        s = np.frombuffer(case["bases"].encode(), np.uint8).copy()
+        g0 = np.full(len(s), case["gop_in"], np.uint8) if isinstance(case["gop_in"], int) else np.array(case["gop_in"], np.uint8)
+        a, b = g0.copy(), g0.copy()
+        H.rovaca_amd_apply_pcr_error_model(s, a, len(s), case["model"])
+        O.phmm_oracle_apply_pcr_error_model(s, b, len(s), case["model"])
+        assert a.tolist() == case["expect"], (case["bases"], case["model"], case["why"])
+        assert b.tolist() == case["expect"]
+
+
+def test_known_answers_quality_modification():
+    H, O = hostapi.lib(), oracle.lib()
+    for case in _fixture()["modify_read_qualities"]:
+        a = np.array(case["qual"], np.uint8)
+        b = a.copy()
+        H.rovaca_amd_modify_read_qualities(a, len(a), case["mapq"], case["threshold"])
+        O.phmm_oracle_modify_quals(b, len(b), case["mapq"], case["threshold"])
+        assert a.tolist() == case["expect"], case["why"]
+        assert b.tolist() == case["expect"]
+
+
+def test_known_answers_filter_and_normalise():
+    H, O = hostapi.lib(), oracle.lib()
+    fx = _fixture()
+    for case in fx["poorly_modelled_reads"]:
+        n = len(case["read_len"])
+        # two haplotypes per read: the best one decides
+        lik = np.array([[b, b - 3.0] for b in case["best"]], np.float64).reshape(-1)
+        drop, keep = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        H.rovaca_amd_poorly_modelled_reads(lik.copy(), np.array(case["read_len"], np.int32), n, 2, drop)
+        O.phmm_oracle_filter(lik.copy(), np.array(case["read_len"], np.uint32), n, 2, keep)
+        assert drop.tolist() == case["drop"], case["why"]
+        assert (1 - keep).tolist() == case["drop"]
+    for case in fx["normalize_likelihoods"]:
+        want = np.array([_f(v) for v in case["expect"]])
+        for fn in (H.rovaca_amd_normalize_likelihoods, O.phmm_oracle_normalize):
+            v = np.array([_f(x) for x in case["row"]])
+            fn(v, 1, len(v))
+            assert np.array_equal(v, want, equal_nan=True), (case["why"], v)
