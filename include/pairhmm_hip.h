@@ -149,6 +149,16 @@ int phmm_multi_download(phmm_multi *m, phmm_multi_resident *rb, float *out_raw_f
 int phmm_multi_shard_cells(const phmm_multi_resident *rb, uint64_t *cells /*[n_devices], nullable*/, uint64_t *pairs /*nullable*/);
 void phmm_multi_release(phmm_multi *m, phmm_multi_resident *rb);
 
+/* ---- allele marginalisation, the step right after the seam ----
+ * One sample of AlleleLikelihoods::marginal_likelihoods_direct (genotype/allele_likelihoods.hpp:702-732), called from
+ * germline_genotying_engine.cpp:143 through marginalize (:188-217): out[a'][r] = max over the old alleles a with
+ * old2new[a] == a' of old[a][r], -inf where nothing maps to a'; entries equal to -1 (s_missing_index, :26) are skipped.
+ * old: [n_old][stride] host doubles with evidence_count <= stride valid values per row; out: [n_new][evidence_count].
+ * Exact (a maximum of doubles).  device_ms (nullable): HIP-event time of the kernel.  The drop-in adapter does this on the
+ * host (rovaca::marginal_likelihoods_direct, rovaca_amd/host): a region's matrix is a few kilobytes -- DESIGN.md section 6. */
+int phmm_marginalize(phmm_context *ctx, const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count,
+                     const int32_t *old2new, uint32_t n_new, double *out, double *device_ms);
+
 /* ---- lookup tables the engine built on the host (core/context.h:13-189), for parity checks ---- */
 #define PHMM_MM_TABLE_SIZE 32640 /* ((254 + 1) * (254 + 2)) >> 1 */
 int phmm_get_tables(float *ph2pr_f32 /*[128]*/, float *mm_f32 /*[32640]*/, double *ph2pr_f64 /*[128]*/,

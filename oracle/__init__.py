@@ -77,6 +77,9 @@ def lib():
     L.phmm_oracle_normalize.restype = None
     L.phmm_oracle_filter.argtypes = [f64p, u32p, C.c_uint32, C.c_uint32, u8p]
     L.phmm_oracle_filter.restype = C.c_uint32
+    L.phmm_oracle_marginalize.argtypes = [f64p, C.c_uint32, C.c_uint32, C.c_uint32, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
+                                          C.c_uint32, f64p]
+    L.phmm_oracle_marginalize.restype = None
     L.phmm_oracle_call_region.argtypes = [u8p, u8p, u32p, u32p, u8p, C.c_uint32, u8p, u32p, u32p, C.c_uint32,
                                           C.c_int32, C.c_int, f64p, u32p]
     L.phmm_oracle_call_region.restype = C.c_uint32

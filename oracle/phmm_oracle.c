@@ -500,6 +500,29 @@ uint32_t phmm_oracle_filter(const double *lik, const uint32_t *read_len, uint32_
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * next-3  allele marginalisation -- genotype/allele_likelihoods.hpp:702-732 (marginal_likelihoods_direct), one
+ * sample: every new allele's row starts at -inf (:712); each old allele whose map entry is not s_missing_index
+ * (-1, :26, :717-719) raises the new row wherever its value is strictly greater (:724-727), old alleles in
+ * ascending order.  A NaN never compares greater, so it is skipped.  old is [n_old][stride] with evidence_count
+ * valid values per row (the reference's rows may be wider than the evidence list), out is [n_new][evidence_count].
+ * ---------------------------------------------------------------------------------------------- */
+void phmm_oracle_marginalize(const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count, const int32_t *old2new,
+                             uint32_t n_new, double *out)
+{
+    for (size_t k = 0; k < (size_t)n_new * evidence_count; k++) out[k] = -INFINITY;
+    for (uint32_t a = 0; a < n_old; a++) {
+        int32_t na = old2new[a];
+        if (na == -1) continue;
+        const double *src = old + (size_t)a * stride;
+        double *dst = out + (size_t)na * evidence_count;
+        for (uint32_t r = 0; r < evidence_count; r++) {
+            double v = src[r];
+            if (v > dst[r]) dst[r] = v;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * H1/H2  one region end to end -- pairhmm_internal.cpp:505-594 (call_old_pairhmm); the AVX-512 driver
  * (:596-753) differs only in how reads are packed into lanes, which does not change any per-pair
  * value.

@@ -62,6 +62,8 @@ void phmm_oracle_apply_pcr_error_model(const uint8_t *bases, uint8_t *gap_qual, 
  * filter returns the number of surviving reads and writes keep[i] in {0,1}. */
 void phmm_oracle_normalize(double *lik, uint32_t n_reads, uint32_t n_haps);
 uint32_t phmm_oracle_filter(const double *lik, const uint32_t *read_len, uint32_t n_reads, uint32_t n_haps, uint8_t *keep);
+void phmm_oracle_marginalize(const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count, const int32_t *old2new,
+                             uint32_t n_new, double *out);
 
 /* H1/H2 end to end for one region: reads x haps -> [hap][read] matrix exactly as call_old_pairhmm /
  * call_new_pairhmm002 return it (row width = n_reads, valid prefix = survivors, tail NaN).

@@ -20,7 +20,7 @@ EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy
            "phmm_get_tables", "phmm_download_read_table",
            "phmm_create_multi", "phmm_destroy_multi", "phmm_multi_device_count", "phmm_multi_device_id", "phmm_multi_compute",
            "phmm_multi_upload", "phmm_multi_sweep", "phmm_multi_synchronize", "phmm_multi_sweep_timed", "phmm_multi_download",
-           "phmm_multi_shard_cells", "phmm_multi_release")
+           "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize")
 
 
 class PhmmBatch(C.Structure):
@@ -108,6 +108,9 @@ def lib():
     L.phmm_multi_shard_cells.restype = C.c_int
     L.phmm_multi_release.argtypes = [C.c_void_p, C.c_void_p]
     L.phmm_multi_release.restype = None
+    L.phmm_marginalize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                   C.POINTER(C.c_double)]
+    L.phmm_marginalize.restype = C.c_int
     _LIB = L
     return L
 
@@ -215,6 +218,18 @@ class Engine:
         r = Resident(self, h, batch.n_reads * batch.n_haps if cross else batch.n_pairs)
         r.read_bytes = int(batch.read_bases.shape[0])
         return r
+
+    def marginalize(self, old, old2new, n_new, evidence_count=None):
+        """Device form of marginal_likelihoods_direct (one sample): old [n_old][stride] -> ([n_new][evidence_count], kernel ms)."""
+        old = np.ascontiguousarray(old, np.float64)
+        n_old, stride = old.shape
+        ev = stride if evidence_count is None else int(evidence_count)
+        m = np.ascontiguousarray(old2new, np.int32)
+        out = np.empty((n_new, ev), np.float64)
+        ms = C.c_double()
+        _check(lib().phmm_marginalize(self.handle, _ptr(old), n_old, stride, ev, _ptr(m), n_new, _ptr(out), C.byref(ms)),
+               "phmm_marginalize")
+        return out, ms.value
 
     def synchronize(self):
         _check(lib().phmm_synchronize(self.handle), "phmm_synchronize")

@@ -138,6 +138,8 @@ struct phmm_context
     hipEvent_t chunk_up[2] = {nullptr, nullptr}, chunk_done[2] = {nullptr, nullptr};
     std::vector<uint32_t> bin_hist, bin_slot;  // host scratch of the length binning, kept between calls
     std::vector<hipEvent_t> timing;            // event pool of phmm_sweep_timed
+    DevBuf<uint8_t> marg_dev;                  // phmm_marginalize: [old matrix][index map][result]
+    HostBuf marg_stage;
 };
 
 struct Bin
@@ -1753,6 +1755,42 @@ int phmm_multi_compute(phmm_multi *m, const phmm_batch *b, float *out_raw_f32, d
     return PHMM_OK;
 }
 
+// ---- allele marginalisation ----
+int phmm_marginalize(phmm_context *c, const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count,
+                     const int32_t *old2new, uint32_t n_new, double *out, double *device_ms)
+{
+    if (!c || !old2new || (n_old && !old) || (n_new && evidence_count && !out) || evidence_count > stride)
+        return fail(PHMM_E_INVALID, "phmm_marginalize: bad arguments");
+    for (uint32_t a = 0; a < n_old; ++a)
+        if (old2new[a] != -1 && (old2new[a] < 0 || (uint32_t)old2new[a] >= n_new))
+            return fail(PHMM_E_INVALID, "phmm_marginalize: old allele %u maps to %d, outside [0, %u)", a, old2new[a], n_new);
+    if (device_ms) *device_ms = 0.0;
+    if (n_new == 0 || evidence_count == 0) return PHMM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_b = (size_t)n_old * stride * sizeof(double), map_b = ((size_t)n_old * sizeof(int32_t) + 7) & ~size_t(7);
+    const size_t out_b = (size_t)n_new * evidence_count * sizeof(double);
+    HIP_TRY(c->marg_dev.alloc(in_b + map_b + out_b + 8));
+    HIP_TRY(c->marg_stage.ensure(in_b + map_b + out_b + 8));
+    uint8_t *hs = static_cast<uint8_t *>(c->marg_stage.p);
+    if (in_b) memcpy(hs, old, in_b);
+    if (n_old) memcpy(hs + in_b, old2new, (size_t)n_old * sizeof(int32_t));
+    if (in_b + map_b) HIP_TRY(hipMemcpyAsync(c->marg_dev.p, hs, in_b + map_b, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(phmm::launch_marginalize(reinterpret_cast<const double *>(c->marg_dev.p), n_old, stride, evidence_count,
+                                     reinterpret_cast<const int32_t *>(c->marg_dev.p + in_b), n_new,
+                                     reinterpret_cast<double *>(c->marg_dev.p + in_b + map_b), c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(hs + in_b + map_b, c->marg_dev.p + in_b + map_b, out_b, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, hs + in_b + map_b, out_b);
+    if (device_ms) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        *device_ms = ms;
+    }
+    return PHMM_OK;
+}
+
 }  // namespace impl
 
 // ----------------------------------------------------------------------------------------------------
@@ -1820,6 +1858,12 @@ int phmm_download_read_table(phmm_context *c, phmm_resident *rb, uint8_t *q, uin
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *raw, double *l10, phmm_stats *st)
 {
     return guarded("phmm_compute", [&] { return impl::phmm_compute(c, b, raw, l10, st); });
+}
+
+int phmm_marginalize(phmm_context *c, const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count, const int32_t *old2new,
+                     uint32_t n_new, double *out, double *device_ms)
+{
+    return guarded("phmm_marginalize", [&] { return impl::phmm_marginalize(c, old, n_old, stride, evidence_count, old2new, n_new, out, device_ms); });
 }
 
 int phmm_create_multi(const int *device_ids, int n, phmm_multi **out)

@@ -92,6 +92,9 @@ struct SetupArgs
     uint32_t *rescue_count;  // kRescueQueues counters, zeroed if non-null
 };
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s);
+// allele marginalisation (pairhmm_marginal.hip): device pointers; old [n_old][stride], out [n_new][evidence_count]
+hipError_t launch_marginalize(const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count, const int32_t *old2new,
+                              uint32_t n_new, double *out, hipStream_t s);
 
 }  // namespace phmm
 #endif

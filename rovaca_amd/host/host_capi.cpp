@@ -27,6 +27,24 @@ void rovaca_amd_normalize_likelihoods(double *lik, uint32_t n_reads, uint32_t n_
 {
     rovaca_amd::normalize_likelihoods(lik, n_reads, n_haps);
 }
+void rovaca_amd_marginal_likelihoods_direct(const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count,
+                                            const int32_t *old2new, uint32_t n_new, double *out)
+{
+    rovaca_amd::marginal_likelihoods_direct(old, n_old, stride, evidence_count, old2new, n_new, out);
+}
+// the same through the adapter-level function, which speaks the reference's types (pmr vectors from an arena)
+void rovaca_amd_marginalize_through_adapter(const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count,
+                                            const int32_t *old2new, uint32_t n_new, double *out)
+{
+    std::pmr::monotonic_buffer_resource arena;
+    rovaca::DoubleVector2D values(&arena);
+    for (uint32_t a = 0; a < n_old; ++a)  // (the pmr outer vector hands its resource to the row it constructs)
+        values.emplace_back(old + (size_t)a * stride, old + (size_t)(a + 1) * stride);
+    rovaca::Int32Vector map(old2new, old2new + n_old, &arena);
+    const rovaca::DoubleVector2D res = rovaca::marginal_likelihoods_direct(values, evidence_count, n_new, map, &arena);
+    for (uint32_t a = 0; a < n_new; ++a)
+        for (uint32_t r = 0; r < evidence_count; ++r) out[(size_t)a * evidence_count + r] = res[a][r];
+}
 uint32_t rovaca_amd_poorly_modelled_reads(const double *lik, const int32_t *read_len, uint32_t n_reads, uint32_t n_haps,
                                           uint8_t *drop)
 {

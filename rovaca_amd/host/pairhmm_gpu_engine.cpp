@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -410,6 +411,24 @@ DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32
         ++k;
     }
     return final_likelihood;
+}
+
+DoubleVector2D marginal_likelihoods_direct(const DoubleVector2D &old_sample_values, size_t evidence_count, size_t new_allele_count,
+                                           const Int32Vector &old2new_idx_map, pMemoryPool pool)
+{
+    // allele_likelihoods.hpp:712: every new row starts at -inf
+    DoubleVector2D result(new_allele_count, DoubleVector(evidence_count, -std::numeric_limits<double>::infinity(), pool), pool);
+    const size_t old_allele_count = old2new_idx_map.size();
+    for (size_t ai = 0; ai < old_allele_count; ++ai) {
+        const int32_t target = old2new_idx_map[ai];
+        if (target == rovaca_amd::kMissingAlleleIndex) continue;  // :717-719
+        // one old row onto one new row: the flat routine with a single allele keeps the reference's comparison (:724-727)
+        const DoubleVector &old_lk = old_sample_values.at(ai);
+        DoubleVector &new_lk = result.at((size_t)target);
+        for (size_t ri = 0; ri < evidence_count; ++ri)
+            if (old_lk[ri] > new_lk[ri]) new_lk[ri] = old_lk[ri];
+    }
+    return result;
 }
 
 }  // namespace rovaca

@@ -41,6 +41,14 @@ bool init_pairhmm_ptr_gpu(int device_id = -1);
 // call_pairhmm concurrently are coalesced into one device batch per round trip.  ROVACA_AMD_PAIRHMM_BATCHING=0 disables it.
 void gpu_pairhmm_batching_stats(uint64_t *regions, uint64_t *submissions);
 
+// the step right after the seam.  One sample of AlleleLikelihoods::marginal_likelihoods_direct
+// (genotype/allele_likelihoods.hpp:702-732): the read x haplotype matrix collapsed onto a smaller allele set by a maximum
+// over the old alleles that map to each new one.  Same values, bit for bit (a maximum of doubles); the rows of the result
+// come from `pool` and are `evidence_count` long.  Measured (tools/measure_marginalize.py): a region's matrix is a few
+// kilobytes and the host loop takes about a microsecond, a device round trip tens -- it runs on the host, next to H8.
+DoubleVector2D marginal_likelihoods_direct(const DoubleVector2D &old_sample_values, size_t evidence_count, size_t new_allele_count,
+                                           const Int32Vector &old2new_idx_map, pMemoryPool pool);
+
 // true once init_pairhmm_ptr_gpu succeeded (the caller skips its AVX-512 read pre-sort, haplotypecaller_engine.cpp:245-248)
 bool gpu_pairhmm_active();
 

@@ -3,6 +3,7 @@
 #include "pairhmm_host_logic.h"
 
 #include <algorithm>
+#include <limits>
 #include <cmath>
 #include <cstring>
 
@@ -106,6 +107,20 @@ std::vector<size_t> poorly_modelled_reads(const double *lik, const int32_t *read
         if (best < worst_ok) drop.push_back(r);
     }
     return drop;
+}
+
+void marginal_likelihoods_direct(const double *old, size_t n_old, size_t stride, size_t evidence_count, const int32_t *old2new,
+                                 size_t n_new, double *out)
+{
+    std::fill(out, out + n_new * evidence_count, -std::numeric_limits<double>::infinity());  // allele_likelihoods.hpp:712
+    for (size_t a = 0; a < n_old; ++a) {  // old alleles in ascending order, as the reference walks them (:715)
+        const int32_t target = old2new[a];
+        if (target == kMissingAlleleIndex) continue;
+        const double *src = old + a * stride;
+        double *dst = out + (size_t)target * evidence_count;
+        for (size_t r = 0; r < evidence_count; ++r)
+            if (src[r] > dst[r]) dst[r] = src[r];  // strict: a NaN is never taken, the first of two equal values stays (:724-727)
+    }
 }
 
 }  // namespace rovaca_amd

@@ -32,5 +32,14 @@ void normalize_likelihoods(double *lik, size_t n_reads, size_t n_haps);
 // returns indices of reads to DROP, ascending
 std::vector<size_t> poorly_modelled_reads(const double *lik, const int32_t *read_len, size_t n_reads, size_t n_haps);
 
+
+// next-3  genotype/allele_likelihoods.hpp:702-732 (marginal_likelihoods_direct), one sample:
+// out[a'][r] = max over the old alleles a with old2new[a] == a' of old[a][r], -inf where no old allele maps to a'; entries
+// of old2new equal to kMissingAlleleIndex (s_missing_index, :26) are skipped.  old is [n_old][stride] (the reference's rows
+// are as wide as the ORIGINAL read count; only the first evidence_count values are evidence), out is [n_new][evidence_count].
+constexpr int32_t kMissingAlleleIndex = -1;
+void marginal_likelihoods_direct(const double *old, size_t n_old, size_t stride, size_t evidence_count, const int32_t *old2new,
+                                 size_t n_new, double *out);
+
 }  // namespace rovaca_amd
 #endif

@@ -45,6 +45,7 @@ typedef struct Bases Bases, *pBases;  // genotype/forward.h:24
 
 typedef class ReadRecord ReadRecord, *pReadRecord;
 typedef class Haplotype Haplotype, *pHaplotype;
+typedef std::pmr::vector<int32_t> Int32Vector;  // genotype/forward.h:75
 typedef std::pmr::vector<double> DoubleVector;
 typedef std::pmr::vector<DoubleVector> DoubleVector2D;
 typedef std::pmr::vector<pReadRecord> ReadVector;

@@ -18,7 +18,7 @@ PCR = {"NONE": 0, "HOSTILE": 1, "AGGRESSIVE": 2, "CONSERVATIVE": 3}  # common/en
 
 EXPORTS = ("rovaca_amd_modify_read_qualities", "rovaca_amd_tandem_repeat_length", "rovaca_amd_apply_pcr_error_model",
            "rovaca_amd_normalize_likelihoods", "rovaca_amd_poorly_modelled_reads", "rovaca_amd_init_pairhmm_ptr_gpu",
-           "rovaca_amd_call_region", "rovaca_amd_batching_stats")
+           "rovaca_amd_call_region", "rovaca_amd_batching_stats", "rovaca_amd_marginal_likelihoods_direct", "rovaca_amd_marginalize_through_adapter")
 
 
 def lib():
@@ -38,6 +38,10 @@ def lib():
     L.rovaca_amd_normalize_likelihoods.restype = None
     L.rovaca_amd_poorly_modelled_reads.argtypes = [f64p, i32p, C.c_uint32, C.c_uint32, u8p]
     L.rovaca_amd_poorly_modelled_reads.restype = C.c_uint32
+    L.rovaca_amd_marginal_likelihoods_direct.argtypes = [f64p, C.c_uint32, C.c_uint32, C.c_uint32, i32p, C.c_uint32, f64p]
+    L.rovaca_amd_marginal_likelihoods_direct.restype = None
+    L.rovaca_amd_marginalize_through_adapter.argtypes = L.rovaca_amd_marginal_likelihoods_direct.argtypes
+    L.rovaca_amd_marginalize_through_adapter.restype = None
     L.rovaca_amd_init_pairhmm_ptr_gpu.argtypes = [C.c_int]
     L.rovaca_amd_init_pairhmm_ptr_gpu.restype = C.c_int
     L.rovaca_amd_call_region.argtypes = [u8p, u8p, u32p, u32p, u8p, C.c_uint32, u8p, u32p, u32p, C.c_uint32, C.c_int32,
@@ -77,3 +81,15 @@ def call_region(read_bases, read_qual, read_off, read_len, read_mq, hap_bases, h
     if n < 0:
         raise RuntimeError("rovaca::call_pairhmm is not installed: init_pairhmm_ptr_gpu() found no device")
     return out, surv[:n].copy()
+
+
+def marginal_likelihoods_direct(old, old2new, n_new, evidence_count=None, through_adapter=False):
+    """old: [n_old][stride] doubles; returns [n_new][evidence_count] (allele_likelihoods.hpp:702-732, one sample).
+    through_adapter: go through rovaca::marginal_likelihoods_direct (pmr vectors) instead of the flat routine."""
+    old = np.ascontiguousarray(old, np.float64)
+    n_old, stride = old.shape
+    ev = stride if evidence_count is None else int(evidence_count)
+    out = np.empty((n_new, ev), np.float64)
+    fn = lib().rovaca_amd_marginalize_through_adapter if through_adapter else lib().rovaca_amd_marginal_likelihoods_direct
+    fn(old.reshape(-1), n_old, stride, ev, np.ascontiguousarray(old2new, np.int32), n_new, out.reshape(-1))
+    return out
