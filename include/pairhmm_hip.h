@@ -22,13 +22,13 @@
 extern "C" {
 #endif
 
-#define PHMM_ABI_VERSION 3
+#define PHMM_ABI_VERSION 4
 
 /* status codes (0 = ok).  Nothing is thrown across this boundary. */
 enum {
     PHMM_OK = 0,
     PHMM_E_INVALID = 1,    /* bad argument: null pointer, zero-length read/haplotype, index out of range, read too long */
-    PHMM_E_NO_DEVICE = 2,  /* no usable HIP device: there is NO CPU fallback in this library */
+    PHMM_E_NO_DEVICE = 2,  /* no usable HIP device: a device context has NO CPU fallback (the CPU backend is asked for by name) */
     PHMM_E_HIP = 3,        /* a HIP runtime call failed; see phmm_last_error() */
     PHMM_E_NOMEM = 4
 };
@@ -97,6 +97,13 @@ int phmm_device_count(void);
 /* device_id >= 0.  stream: a hipStream_t to run on, or NULL to create a private one.  One context drives ONE device (its
  * stream set, staging and tables live there); for several devices see phmm_create_multi below. */
 int phmm_create(int device_id, void *stream, phmm_context **out);
+/* BASELINE.json config 1 / SURVEY.md 8b ("same entry point must have a CPU backend"): a context that computes on the host --
+ * this repository's own scalar and AVX2 + FMA inter-pair kernels (rovaca_amd/csrc/pairhmm_cpu.cpp), the same numerics contract
+ * and the same bits as the device path.  n_threads 0 = all hardware threads; allow_simd 0 forces the scalar kernel.  Every
+ * entry point that takes a phmm_context works on it (a resident batch is then a host copy).  It is a backend one asks for by
+ * name: a device context (phmm_create) never falls back to it. */
+int phmm_create_cpu(int n_threads, int allow_simd, phmm_context **out);
+const char *phmm_backend_name(const phmm_context *ctx); /* "hip gfx950", "avx2+fma inter-pair (...)", "scalar" */
 void phmm_destroy(phmm_context *ctx);
 const char *phmm_last_error(void); /* thread-local text of the last failure */
 

@@ -20,7 +20,7 @@ EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy
            "phmm_get_tables", "phmm_download_read_table",
            "phmm_create_multi", "phmm_destroy_multi", "phmm_multi_device_count", "phmm_multi_device_id", "phmm_multi_compute",
            "phmm_multi_upload", "phmm_multi_sweep", "phmm_multi_synchronize", "phmm_multi_sweep_timed", "phmm_multi_download",
-           "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize")
+           "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize", "phmm_create_cpu", "phmm_backend_name")
 
 
 class PhmmBatch(C.Structure):
@@ -111,6 +111,10 @@ def lib():
     L.phmm_marginalize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                    C.POINTER(C.c_double)]
     L.phmm_marginalize.restype = C.c_int
+    L.phmm_create_cpu.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.phmm_create_cpu.restype = C.c_int
+    L.phmm_backend_name.argtypes = [C.c_void_p]
+    L.phmm_backend_name.restype = C.c_char_p
     _LIB = L
     return L
 
@@ -244,6 +248,20 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+class CpuEngine(Engine):
+    """BASELINE config 1: the CPU backend of the same C ABI (phmm_create_cpu) -- this repository's scalar and AVX2 + FMA
+    kernels, asked for by name; a device Engine never falls back to it."""
+
+    def __init__(self, n_threads=0, simd=True):
+        h = C.c_void_p()
+        _check(lib().phmm_create_cpu(int(n_threads), 1 if simd else 0, C.byref(h)), "phmm_create_cpu")
+        self.handle = h
+
+    @property
+    def backend(self):
+        return lib().phmm_backend_name(self.handle).decode()
 
 
 class MultiResident:

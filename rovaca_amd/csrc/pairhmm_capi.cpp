@@ -18,6 +18,8 @@
 #include <vector>
 
 #include "../../include/pairhmm_hip.h"
+#include "../host/pairhmm_host_logic.h"
+#include "pairhmm_cpu.h"
 #include "pairhmm_device.h"
 #include "pairhmm_tables.h"
 
@@ -119,6 +121,10 @@ struct HostBuf
 
 struct phmm_context
 {
+    // BASELINE config 1: a context made by phmm_create_cpu computes on the host (pairhmm_cpu.cpp) and owns no HIP object
+    bool cpu = false;
+    unsigned cpu_threads = 1;
+    bool cpu_simd = true;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -204,8 +210,21 @@ constexpr uint32_t kWideMaxPairs = 1536;       // single-pass launches up to thi
 constexpr uint32_t kRescueMaxTeams = 4096;    // workgroups of the fp64 re-run (they stride over the rescue queue)
 constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
 
+// a batch kept by a CPU context: deep copies of the tables (prepared: H3/H4 already applied when the batch asked for it)
+struct CpuBatch
+{
+    std::vector<uint8_t> bases, qual, ins, del, gcp, haps;
+    std::vector<uint32_t> roff, rlen, hoff, hlen, pr, ph;
+    std::vector<float> raw32;
+    std::vector<double> raw64;
+    std::vector<uint8_t> rescued;
+    phmm_batch view{};
+};
+
 struct phmm_resident
 {
+    CpuBatch *cpu = nullptr;
+    ~phmm_resident() { delete cpu; }
     uint64_t n_pairs = 0, cells = 0;
     uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
     bool uniform_gcp = false;
@@ -329,9 +348,28 @@ int phmm_create(int device_id, void *stream, phmm_context **out)
     return PHMM_OK;
 }
 
+int phmm_create_cpu(int n_threads, int allow_simd, phmm_context **out)
+{
+    if (!out || n_threads < 0) return fail(PHMM_E_INVALID, "phmm_create_cpu: bad arguments");
+    *out = nullptr;
+    phmm_context *c = new phmm_context();
+    c->cpu = true;
+    const unsigned hw = std::thread::hardware_concurrency();
+    c->cpu_threads = n_threads > 0 ? (unsigned)n_threads : std::max(1u, hw);
+    c->cpu_simd = allow_simd != 0;
+    (void)phmm::host_tables();  // built once, under std::call_once
+    *out = c;
+    return PHMM_OK;
+}
+
 void phmm_destroy(phmm_context *c)
 {
     if (!c) return;
+    if (c->cpu) {
+        delete c->scratch;
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -356,6 +394,7 @@ void phmm_destroy(phmm_context *c)
 int phmm_synchronize(phmm_context *c)
 {
     if (!c) return fail(PHMM_E_INVALID, "null context");
+    if (c->cpu) return PHMM_OK;  // the CPU backend computes inside the calls
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PHMM_OK;
 }
@@ -363,7 +402,7 @@ int phmm_synchronize(phmm_context *c)
 void phmm_release(phmm_context *c, phmm_resident *rb)
 {
     if (!rb) return;
-    if (c) {
+    if (c && !c->cpu) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
@@ -784,13 +823,140 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, 
     return PHMM_OK;
 }
 
+// ---- CPU backend (phmm_create_cpu): the same entry points, computed on the host by pairhmm_cpu.cpp ----
+static int cpu_check_batch(const phmm_batch *b, uint64_t *n_pairs)
+{
+    if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
+        return fail(PHMM_E_INVALID, "phmm_upload: pair_read and pair_hap must both be given or both be NULL");
+    const uint64_t n = b->pair_read ? b->n_pairs : (uint64_t)b->n_reads * b->n_haps;
+    if (n > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_upload: more than 2^32 pairs in one batch");
+    if (n && (!b->read_bases || !b->read_qual || !b->read_off || !b->read_len || !b->hap_bases || !b->hap_off || !b->hap_len))
+        return fail(PHMM_E_INVALID, "phmm_upload: null table pointer");
+    if (n && !b->prep && (!b->read_ins || !b->read_del || !b->read_gcp))
+        return fail(PHMM_E_INVALID, "phmm_upload: null gap-penalty array (and no phmm_read_prep given)");
+    if (b->prep && (!b->prep->read_mapq || b->prep->pcr_model < 0 || b->prep->pcr_model > 3))
+        return fail(PHMM_E_INVALID, "phmm_upload: bad phmm_read_prep");
+    for (uint32_t r = 0; r < b->n_reads; ++r)
+        if (b->read_len[r] == 0) return fail(PHMM_E_INVALID, "phmm_upload: read %u has length 0", r);
+    for (uint32_t h = 0; h < b->n_haps; ++h)
+        if (b->hap_len[h] == 0) return fail(PHMM_E_INVALID, "phmm_upload: haplotype %u has length 0", h);
+    *n_pairs = n;
+    return PHMM_OK;
+}
+
+// deep copy with the read table PREPARED: a batch that asks for read preparation gets H3 + H4 here (the same routines the
+// drop-in adapter's host logic uses: pairhmm_internal.cpp:434-439, :65-159)
+static int cpu_keep(const phmm_batch *b, CpuBatch *k)
+{
+    uint64_t read_bytes = 0, hap_bytes = 0;
+    for (uint32_t r = 0; r < b->n_reads; ++r) read_bytes = std::max<uint64_t>(read_bytes, (uint64_t)b->read_off[r] + b->read_len[r]);
+    for (uint32_t h = 0; h < b->n_haps; ++h) hap_bytes = std::max<uint64_t>(hap_bytes, (uint64_t)b->hap_off[h] + b->hap_len[h]);
+    k->bases.assign(b->read_bases, b->read_bases + read_bytes);
+    k->qual.assign(b->read_qual, b->read_qual + read_bytes);
+    k->roff.assign(b->read_off, b->read_off + b->n_reads);
+    k->rlen.assign(b->read_len, b->read_len + b->n_reads);
+    k->haps.assign(b->hap_bases, b->hap_bases + hap_bytes);
+    k->hoff.assign(b->hap_off, b->hap_off + b->n_haps);
+    k->hlen.assign(b->hap_len, b->hap_len + b->n_haps);
+    if (b->prep) {
+        k->ins.assign(read_bytes, b->prep->gap_open);
+        k->gcp.assign(read_bytes, b->prep->gap_cont);
+        for (uint32_t r = 0; r < b->n_reads; ++r) {
+            const uint32_t o = k->roff[r], n = k->rlen[r];
+            rovaca_amd::modify_read_qualities(k->qual.data() + o, n, b->prep->read_mapq[r], b->prep->min_quality_threshold);
+            rovaca_amd::apply_pcr_error_model(k->bases.data() + o, k->ins.data() + o, n, b->prep->pcr_model);
+        }
+        k->del = k->ins;  // pairhmm_internal.cpp:425
+    }
+    else {
+        k->ins.assign(b->read_ins, b->read_ins + read_bytes);
+        k->del.assign(b->read_del, b->read_del + read_bytes);
+        k->gcp.assign(b->read_gcp, b->read_gcp + read_bytes);
+    }
+    if (b->pair_read) {
+        k->pr.assign(b->pair_read, b->pair_read + b->n_pairs);
+        k->ph.assign(b->pair_hap, b->pair_hap + b->n_pairs);
+    }
+    phmm_batch &v = k->view;
+    v = phmm_batch{};
+    v.n_reads = b->n_reads;
+    v.n_haps = b->n_haps;
+    v.n_pairs = b->pair_read ? b->n_pairs : 0;
+    v.read_bases = k->bases.data();
+    v.read_qual = k->qual.data();
+    v.read_ins = k->ins.data();
+    v.read_del = k->del.data();
+    v.read_gcp = k->gcp.data();
+    v.read_off = k->roff.data();
+    v.read_len = k->rlen.data();
+    v.hap_bases = k->haps.data();
+    v.hap_off = k->hoff.data();
+    v.hap_len = k->hlen.data();
+    v.pair_read = b->pair_read ? k->pr.data() : nullptr;
+    v.pair_hap = b->pair_read ? k->ph.data() : nullptr;
+    return PHMM_OK;
+}
+
+static int cpu_upload(phmm_context *, const phmm_batch *b, phmm_resident *rb)
+{
+    uint64_t n = 0;
+    int rc = cpu_check_batch(b, &n);
+    if (rc != PHMM_OK) return rc;
+    delete rb->cpu;
+    rb->cpu = new CpuBatch();
+    rc = cpu_keep(b, rb->cpu);
+    if (rc != PHMM_OK) return rc;
+    rb->n_pairs = n;
+    rb->n_reads = b->n_reads;
+    rb->n_haps = b->n_haps;
+    rb->cpu->raw32.assign(n, 0.f);
+    rb->cpu->raw64.assign(n, 0.0);
+    rb->cpu->rescued.assign(n, 0);
+    rb->last_rescued = 0;
+    return PHMM_OK;
+}
+
+static int cpu_sweep(phmm_context *c, phmm_resident *rb)
+{
+    if (!rb->cpu) return fail(PHMM_E_INVALID, "phmm_sweep: this batch was not uploaded through a CPU context");
+    CpuBatch &k = *rb->cpu;
+    uint64_t nr = 0, cells = 0;
+    if (phmm::cpu::compute(k.view, c->cpu_threads, c->cpu_simd, k.raw32.data(), k.raw64.data(), k.rescued.data(), &nr, &cells) != 0)
+        return fail(PHMM_E_INVALID, "phmm_sweep: a pair indexes outside the tables");
+    rb->last_rescued = (uint32_t)nr;
+    rb->cells = cells;
+    return PHMM_OK;
+}
+
+static int cpu_download(phmm_context *, phmm_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats)
+{
+    if (!rb->cpu) return fail(PHMM_E_INVALID, "phmm_download: this batch was not uploaded through a CPU context");
+    const CpuBatch &k = *rb->cpu;
+    const uint64_t n = rb->n_pairs;
+    if (out_raw_f32 && n) memcpy(out_raw_f32, k.raw32.data(), n * sizeof(float));
+    if (out_log10)
+        for (uint64_t p = 0; p < n; ++p) {  // pairhmm_internal.cpp:577-585
+            const float x = k.raw32[p];
+            out_log10[p] = x < PHMM_MIN_ACCEPTED_F32 ? log10(k.raw64[p]) - PHMM_LOG10_INITIAL_CONSTANT_F64
+                                                     : (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
+        }
+    if (stats) {
+        *stats = phmm_stats{};
+        stats->cells = rb->cells;
+        stats->n_rescued = rb->last_rescued;
+        stats->kernel_ms = rb->last_kernel_ms;
+        stats->n_launches = 0;
+    }
+    return PHMM_OK;
+}
+
 int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
 {
     if (!c || !b || !out) return fail(PHMM_E_INVALID, "phmm_upload: null argument");
     *out = nullptr;
     phmm_resident *rb = new (std::nothrow) phmm_resident();
     if (!rb) return fail(PHMM_E_NOMEM, "phmm_upload: out of host memory");
-    const int rc = upload_into(c, b, rb);
+    const int rc = c->cpu ? cpu_upload(c, b, rb) : upload_into(c, b, rb);
     if (rc != PHMM_OK) {
         delete rb;
         return rc;
@@ -993,6 +1159,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
 int phmm_sweep(phmm_context *c, phmm_resident *rb)
 {
     if (!c || !rb) return fail(PHMM_E_INVALID, "phmm_sweep: null argument");
+    if (c->cpu) return cpu_sweep(c, rb);
     HIP_TRY(hipSetDevice(c->device));
     int rc = sweep_fp32(c, rb);
     if (rc != PHMM_OK) return rc;
@@ -1002,6 +1169,17 @@ int phmm_sweep(phmm_context *c, phmm_resident *rb)
 int phmm_sweep_timed(phmm_context *c, phmm_resident *rb, int iters, double *ms_per_pass, double *fp32_ms_per_pass)
 {
     if (!c || !rb || iters < 1 || !ms_per_pass) return fail(PHMM_E_INVALID, "phmm_sweep_timed: bad arguments");
+    if (c->cpu) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; ++i) {
+            const int rc = cpu_sweep(c, rb);
+            if (rc != PHMM_OK) return rc;
+        }
+        *ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+        if (fp32_ms_per_pass) *fp32_ms_per_pass = *ms_per_pass;
+        rb->last_kernel_ms = *ms_per_pass;
+        return PHMM_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     // three events per pass (start, after the fp32 launches, end), recorded without waiting; the host waits once per group
     // of passes, so that the passes run back to back as they do without the timing
@@ -1042,6 +1220,7 @@ int phmm_sweep_timed(phmm_context *c, phmm_resident *rb, int iters, double *ms_p
 int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats)
 {
     if (!c || !rb) return fail(PHMM_E_INVALID, "phmm_download: null argument");
+    if (c->cpu) return cpu_download(c, rb, out_raw_f32, out_log10, stats);
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t n = rb->n_pairs;
     const bool want = (out_raw_f32 || out_log10) && n;
@@ -1106,6 +1285,15 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
 int phmm_download_read_table(phmm_context *c, phmm_resident *rb, uint8_t *qual, uint8_t *ins, uint8_t *del, uint8_t *gcp)
 {
     if (!c || !rb) return fail(PHMM_E_INVALID, "phmm_download_read_table: null argument");
+    if (c->cpu) {
+        if (!rb->cpu) return fail(PHMM_E_INVALID, "phmm_download_read_table: this batch was not uploaded through a CPU context");
+        const CpuBatch &k = *rb->cpu;
+        if (qual) memcpy(qual, k.qual.data(), k.qual.size());
+        if (ins) memcpy(ins, k.ins.data(), k.ins.size());
+        if (del) memcpy(del, k.del.data(), k.del.size());
+        if (gcp) memcpy(gcp, k.gcp.data(), k.gcp.size());
+        return PHMM_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = rb->read_qual.n;
     const uint8_t *dp = rb->read_del.p;
@@ -1377,6 +1565,16 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
 {
     if (!c || !b) return fail(PHMM_E_INVALID, "phmm_compute: null argument");
     const auto t0 = std::chrono::steady_clock::now();
+    if (c->cpu) {
+        if (!c->scratch) c->scratch = new phmm_resident();
+        int rc = cpu_upload(c, b, c->scratch);
+        if (rc == PHMM_OK) rc = cpu_sweep(c, c->scratch);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        c->scratch->last_kernel_ms = ms;
+        if (rc == PHMM_OK) rc = cpu_download(c, c->scratch, out_raw_f32, out_log10, stats);
+        if (rc == PHMM_OK && stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    }
     {
         std::vector<ChunkWindow> plan;
         const bool tables_ok = b->read_bases && b->read_qual && b->read_off && b->read_len && b->hap_bases && b->hap_off && b->hap_len &&
@@ -1766,6 +1964,10 @@ int phmm_marginalize(phmm_context *c, const double *old, uint32_t n_old, uint32_
             return fail(PHMM_E_INVALID, "phmm_marginalize: old allele %u maps to %d, outside [0, %u)", a, old2new[a], n_new);
     if (device_ms) *device_ms = 0.0;
     if (n_new == 0 || evidence_count == 0) return PHMM_OK;
+    if (c->cpu) {
+        rovaca_amd::marginal_likelihoods_direct(old, n_old, stride, evidence_count, old2new, n_new, out);
+        return PHMM_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     const size_t in_b = (size_t)n_old * stride * sizeof(double), map_b = ((size_t)n_old * sizeof(int32_t) + 7) & ~size_t(7);
     const size_t out_b = (size_t)n_new * evidence_count * sizeof(double);
@@ -1828,6 +2030,15 @@ int phmm_get_tables(float *a, float *b, double *c, double *d)
 int phmm_create(int device_id, void *stream, phmm_context **out)
 {
     return guarded("phmm_create", [&] { return impl::phmm_create(device_id, stream, out); });
+}
+int phmm_create_cpu(int n_threads, int allow_simd, phmm_context **out)
+{
+    return guarded("phmm_create_cpu", [&] { return impl::phmm_create_cpu(n_threads, allow_simd, out); });
+}
+const char *phmm_backend_name(const phmm_context *c)
+{
+    if (!c) return "";
+    return c->cpu ? phmm::cpu::kernel_name(c->cpu_simd) : "hip gfx950";
 }
 void phmm_destroy(phmm_context *c)
 {
