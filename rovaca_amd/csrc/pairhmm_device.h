@@ -63,7 +63,9 @@ hipError_t launch_striped_f64(int rows_per_lane, bool uniform_gcp, int waves_per
 inline size_t team_lds_bytes(uint32_t plane_words_per_group, int waves_per_team, size_t value_bytes, int lanes_per_pair)
 {
     const size_t groups = 64u / (size_t)lanes_per_pair;
-    return groups * (size_t)plane_words_per_group * sizeof(uint32_t) + (size_t)waves_per_team * groups * 3u * 64u * value_bytes;
+    // planes of the team's pairs, one carry ring per (wave, group), and the waves' progress records (2 rounds x waves x 4 words)
+    return groups * (size_t)plane_words_per_group * sizeof(uint32_t) + (size_t)waves_per_team * groups * 3u * 64u * value_bytes +
+           2u * (size_t)waves_per_team * 4u * sizeof(uint32_t);
 }
 inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t carry_stride, int lanes_per_pair)
 {

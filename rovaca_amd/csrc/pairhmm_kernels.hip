@@ -390,10 +390,20 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
 // supersteps between consecutive stripes of a pair.  The consumer reads three blocks (96 columns) ahead of its first step and
 // the producer's last lane trails its first by G - 1 columns, so 32 * lag >= 95 + G: 4 for 16-lane arrays, 5 (we take 6) for 64.
 template <int G> constexpr uint32_t team_lag() { return G == 64 ? 6u : 4u; }
+// the last carry block a stripe can have put anything into when its last non-skipped superstep was l: the last lane ends that
+// superstep at column 32 l + 32 - (G - 1)
+template <int G> __device__ __forceinline__ uint32_t team_last_block(uint32_t l) { return G == 64 ? (l > 0 ? l - 1u : 0u) : l; }
 
 // G = lanes per pair: 16 (four pairs per wave, DPP row_shr) or 64 (one pair per wave, DPP wave_shr -- for batches with
 // so few pairs that four-per-wave would leave the chip empty: one long-read pair then keeps up to WP waves busy)
 template <typename T, int K, bool UG, int WP, int G>
+#ifndef PHMM_TEAM_ROW_BARRIER_F32
+#define PHMM_TEAM_ROW_BARRIER_F32 1
+#endif
+#ifndef PHMM_TEAM_ROW_BARRIER_F64
+#define PHMM_TEAM_ROW_BARRIER_F64 0
+#endif
+#define PHMM_TEAM_ROW_BARRIER(T) (sizeof(T) == 4 ? PHMM_TEAM_ROW_BARRIER_F32 : PHMM_TEAM_ROW_BARRIER_F64)
 #ifndef PHMM_TEAM_WAVES_F32
 #define PHMM_TEAM_WAVES_F32 4
 #endif
@@ -417,6 +427,9 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
     const uint32_t plane_words = a.lds_words_per_group;
     uint32_t *pl = lds + grp * plane_words;
     T *ring = reinterpret_cast<T *>(lds + kGroups * plane_words) + (static_cast<size_t>(wave) * kGroups + grp) * 3u * kRing;
+    // progress records of the team's waves (several waves per team only): [round parity][wave][stripe + 1, supersteps done,
+    // first superstep with output - 1, last superstep with output - 1 once the stripe is finished]
+    uint32_t *team_rec = reinterpret_cast<uint32_t *>(reinterpret_cast<T *>(lds + kGroups * plane_words) + static_cast<size_t>(WP) * kGroups * 3u * kRing);
     // carry rows: one slab per (team, wave), laid out [column][group][M, X, Y] so that the slab base is wave-uniform (an
     // SGPR pair) and lane 15 writes its three values with one store; stripe v reads the slab of the wave that ran v - 1
     const uint32_t uwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
@@ -439,6 +452,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             const uint32_t *src = a.planes + a.plane_off[h];
             for (uint32_t i = lane + G * wave; i < kPlanes * W; i += G * WP) pl[i] = src[i];
         }
+        if (WP > 1 && threadIdx.x < 2u * WP * 4u) team_rec[threadIdx.x] = 0;  // no wave has begun any stripe of these pairs
         const T init_y = Num<T>::init_const() / static_cast<T>(H);
         const uint32_t n_stripes = valid ? (R + S - 1) / S : 0;
         const int pad = static_cast<int>(n_stripes) * S - static_cast<int>(R);
@@ -506,6 +520,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             preY[q] = 0;
         }
 
+        uint32_t carry_last_blk = 0xFFFFFFFFu;  // the producer stripe wrote nothing (i.e. zeros) behind this block; unknown: all ones
         auto carry_load = [&](uint32_t blk) {  // columns 32 * blk + 1 + lane (+ 16) of the producer's row
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -515,6 +530,11 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     preM[q] = 0;
                     preX[q] = 0;
                     preY[q] = init_y;
+                }
+                else if (blk > carry_last_blk) {
+                    preM[q] = 0;
+                    preX[q] = 0;
+                    preY[q] = 0;
                 }
                 else {
                     const T *src = rbase + (j * kGroups + grp) * 3u;
@@ -627,13 +647,15 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 sumM = 0;
                 sumX = 0;
             }
-            // carry ring: blocks 0 and 1 parked, block 2 in flight
-            carry_load(0);
-            carry_park(0);
-            carry_load(1);
-            carry_park(1);
-            carry_load(2);
-            ring_fetch(1);
+        };
+        // carry ring at the first superstep c0 of a stripe: blocks c0 and c0 + 1 parked, block c0 + 2 in flight
+        auto ring_init = [&](uint32_t c0) {
+            carry_load(c0);
+            carry_park(c0);
+            carry_load(c0 + 1);
+            carry_park(c0 + 1);
+            carry_load(c0 + 2);
+            ring_fetch(32u * c0 + 1u);
             curM = nxtM;
             curX = nxtX;
             curY = nxtY;
@@ -655,7 +677,10 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
                 tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
                 M[k] = tt * prior;
-                __builtin_amdgcn_sched_barrier(0);  // rows in program order, as in the single-pass kernel
+                // fp32: rows in program order, as in the single-pass kernel (four waves per SIMD, issue-bound).  fp64 re-runs and
+                // long reads are the opposite regime -- one or two waves per SIMD, bound by the latency of each row's dependent
+                // mul/fma chain -- so there the compiler may interleave the rows.
+                if (PHMM_TEAM_ROW_BARRIER(T)) __builtin_amdgcn_sched_barrier(0);
             }
             T uM = uM0, uX = uX0;
 #pragma unroll
@@ -694,82 +719,217 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             }
         };
 
-        for (uint32_t g = 0; g < n_super; ++g) {
-            const int32_t tau = static_cast<int32_t>(g) - static_cast<int32_t>(kLag * wave);
-            if (tau >= 0 && static_cast<uint32_t>(tau) < n_rounds * Bs) {
-                const uint32_t round = static_cast<uint32_t>(tau) / Bs, c = static_cast<uint32_t>(tau) % Bs;
-                const uint32_t v = round * WP + wave;
-                if (v < max_stripes) {
-                    if (c == 0) {
-                        stripe_setup(v);
-                    }
-                    else {
-                        carry_park(c + 1);  // block c + 1 joins the ring (block c was parked one superstep ago)
-                        carry_load(c + 2);
-                    }
-                    const uint32_t t0 = 32u * c + 1u;
-                    const uint32_t t1 = min(t0 + 31u, Tmax);
-                    uint32_t Tmin = Tg;  // wave-uniform: the last step at which every group of the wave is still sweeping
-                    if (kGroups > 1) {
-                        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
-                        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
-                    }
-                    Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
-                    // A superstep with nothing but zeros going in -- the carry block it consumes and every value the wave
-                    // holds -- puts nothing but zeros out (each value is a sum of non-negative products of its neighbours,
-                    // and fp32 runs flush-to-zero): write the zero carry columns and move on.  This is where long reads
-                    // spend most of their fp32 pass: a 10-kbp read underflows for good after some 2 000 rows.
-                    bool lane_nz = park_nz[c & 1u] || aM != 0 || aX != 0 || aY != 0 || bM != 0 || bX != 0 || bY != 0;
+        // one superstep (32 columns) of stripe v; returns true when it was skipped as all-zero
+        auto superstep = [&](uint32_t v, uint32_t c, uint32_t c_first) -> bool {
+            if (c == c_first) {
+                ring_init(c);
+            }
+            else {
+                carry_park(c + 1);  // block c + 1 joins the ring (block c was parked one superstep ago)
+                carry_load(c + 2);
+            }
+            const uint32_t t0 = 32u * c + 1u;
+            const uint32_t t1 = min(t0 + 31u, Tmax);
+            uint32_t Tmin = Tg;  // wave-uniform: the last step at which every group of the wave is still sweeping
+            if (kGroups > 1) {
+                Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+                Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
+            }
+            Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
+            // A superstep with nothing but zeros going in -- the carry block it consumes and every value the wave
+            // holds -- puts nothing but zeros out (each value is a sum of non-negative products of its neighbours,
+            // and fp32 runs flush-to-zero): write the zero carry columns and move on.  This is where long reads
+            // spend most of their fp32 pass: a 10-kbp read underflows for good after some 2 000 rows.
+            bool lane_nz = park_nz[c & 1u] || aM != 0 || aX != 0 || aY != 0 || bM != 0 || bX != 0 || bY != 0;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) lane_nz = lane_nz || M[k] != 0 || X[k] != 0 || Y[k] != 0;
-                    if (__ballot(lane_nz && Tg != 0) == 0 && !a.no_early_exit) {
-                        if (Tg != 0 && v + 1 != max_stripes) {
-                            struct V3
-                            {
-                                T m, x, y;
-                            };
-                            for (uint32_t t = t0 + lane; t <= t1 && t <= Tg; t += G) {
-                                if (t > (uint32_t)(G - 1)) *reinterpret_cast<V3 *>(wbase + ((t - (G - 1)) * kGroups + grp) * 3u) = V3{0, 0, 0};
-                            }
+            for (int k = 0; k < K; ++k) lane_nz = lane_nz || M[k] != 0 || X[k] != 0 || Y[k] != 0;
+            bool skipped = false;
+            if (__ballot(lane_nz && Tg != 0) == 0 && !a.no_early_exit) {
+                skipped = true;
+                if (Tg != 0 && v + 1 != max_stripes) {
+                    struct V3
+                    {
+                        T m, x, y;
+                    };
+                    for (uint32_t t = t0 + lane; t <= t1 && t <= Tg; t += G) {
+                        if (t > (uint32_t)(G - 1)) *reinterpret_cast<V3 *>(wbase + ((t - (G - 1)) * kGroups + grp) * 3u) = V3{0, 0, 0};
+                    }
+                }
+                ring_fetch(t1 + 1);
+                curM = nxtM;
+                curX = nxtX;
+                curY = nxtY;
+            }
+            else {
+                masks_reload(t0);
+                if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
+                    // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
+                    if (v + 1 == max_stripes)
+                        superstep_full(t0, std::true_type{});
+                    else
+                        superstep_full(t0, std::false_type{});
+                }
+                else {
+                    for (uint32_t t = t0; t <= t1; ++t) {
+                        ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
+                        if ((t > lane) && (t <= Tg)) {
+                            if (t & 1u)
+                                step(t, aM, aX, aY, bM, bX, bY, last);
+                            else
+                                step(t, bM, bX, bY, aM, aX, aY, last);
                         }
-                        ring_fetch(t1 + 1);
                         curM = nxtM;
                         curX = nxtX;
                         curY = nxtY;
                     }
-                    else {
-                        masks_reload(t0);
-                        if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
-                            // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
-                            if (v + 1 == max_stripes)
-                                superstep_full(t0, std::true_type{});
-                            else
-                                superstep_full(t0, std::false_type{});
-                        }
-                        else {
-                            for (uint32_t t = t0; t <= t1; ++t) {
-                                ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
-                                if ((t > lane) && (t <= Tg)) {
-                                    if (t & 1u)
-                                        step(t, aM, aX, aY, bM, bX, bY, last);
-                                    else
-                                        step(t, bM, bX, bY, aM, aX, aY, last);
-                                }
-                                curM = nxtM;
-                                curX = nxtX;
-                                curY = nxtY;
-                            }
-                        }
-                    }
-                    if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == G - 1) {
-                        const T res = sumM + sumX;
-                        reinterpret_cast<T *>(a.out_raw)[pair] = res;
-                        if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))
-                            a.rescue_list[atomicAdd(a.rescue_count, 1u)] = pair;
-                    }
                 }
             }
-            __syncthreads();  // carry columns written in this superstep are visible to the team before the next one
+            return skipped;
+        };
+        auto write_result = [&]() {
+            if (valid && lane == G - 1) {
+                const T res = sumM + sumX;
+                reinterpret_cast<T *>(a.out_raw)[pair] = res;
+                if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))
+                    a.rescue_list[atomicAdd(a.rescue_count, 1u)] = pair;
+            }
+        };
+
+        if constexpr (WP == 1) {
+            // One wave, all stripes of its pairs one after the other -- and only the BAND of each.  Below the first stripe of a
+            // pair everything is exactly zero until the first non-zero column of the carry arrives from the stripe above, and
+            // again once the band has passed; the wave remembers between which supersteps the stripe it has just finished
+            // produced anything (wave-uniform: the union over the wave's pairs) and starts the next stripe right there instead
+            // of walking -- superstep by superstep, a barrier, a prefetch and a ballot each -- through thousands of zero columns.
+            // Columns behind the band are never written: the consumer is told where they begin (carry_last_blk).  Same bits:
+            // what is not computed is zero, and zero columns add +0 to the sums.
+            uint32_t in_first = 0, in_last = 0xFFFFFFFFu;  // carry blocks the stripe done before this one put anything into: first, last
+            for (uint32_t v = 0; v < max_stripes; ++v) {
+                stripe_setup(v);
+                // a pair's own first stripe has the boundary row above it: non-zero at every column
+                const bool whole_row = a.no_early_exit || __ballot(first && Tg != 0) != 0;
+                const uint32_t c_first = whole_row ? 0u : min(in_first, Bs - 1u);
+                carry_last_blk = whole_row ? 0xFFFFFFFFu : in_last;
+                uint32_t out_first = 0xFFFFFFFFu, out_last = 0;
+                for (uint32_t c = c_first; c < Bs; ++c) {
+                    const bool skipped = superstep(v, c, c_first);
+                    if (!skipped) {
+                        if (out_first == 0xFFFFFFFFu) out_first = c;
+                        out_last = c;
+                    }
+                    else if (!whole_row && c > in_last + 2u) {
+                        break;  // no carry will come any more and the state is zero: the rest of the stripe is zero
+                    }
+                }
+                // Where this stripe's output is non-zero, in carry blocks.  The first non-skipped superstep f was entered with an
+                // all-zero state, so what made it non-zero is carry block f, which lane 0 meets at column 32 f + 1 at the earliest
+                // and the last lane, G - 1 steps later, at that same column: nothing before block f.  The last non-skipped
+                // superstep l leaves the last lane at column 32 l + 32 - (G - 1): block l (G = 16) or l - 1 (G = 64); that block is
+                // complete once superstep l + 1 has run -- it has, the loop leaves only after a skipped superstep or at the end
+                // of the row.  Blocks outside [first, last] are never read by the next stripe (some of them were never written).
+                in_first = out_first == 0xFFFFFFFFu ? Bs : out_first;  // nothing at all: the next stripe has nothing to do either
+                in_last = out_first == 0xFFFFFFFFu ? 0u : team_last_block<G>(out_last);
+                if (v + 1 == max_stripes) write_result();
+                __syncthreads();  // (one wave) the carry written by this stripe is read by the next one
+            }
+        }
+        else if (a.no_early_exit) {
+            // test hook (PHMM_NO_EARLY_EXIT): the plain lock-step pipeline -- every superstep of every stripe, a barrier each
+            for (uint32_t g = 0; g < n_super; ++g) {
+                const int32_t tau = static_cast<int32_t>(g) - static_cast<int32_t>(kLag * wave);
+                if (tau >= 0 && static_cast<uint32_t>(tau) < n_rounds * Bs) {
+                    const uint32_t round = static_cast<uint32_t>(tau) / Bs, c = static_cast<uint32_t>(tau) % Bs;
+                    const uint32_t v = round * WP + wave;
+                    if (v < max_stripes) {
+                        if (c == 0) stripe_setup(v);
+                        superstep(v, c, 0u);
+                        if (c + 1 == Bs && v + 1 == max_stripes) write_result();
+                    }
+                }
+                __syncthreads();  // carry columns written in this superstep are visible to the team before the next one
+            }
+        }
+        else {
+            // Several waves per team, each at its own pace.  Wave w sweeps the stripes w, w + WP, ... and, as in the one-wave
+            // loop above, only the band of each.  What it needs from the wave above (stripe v - 1) travels through four words
+            // of LDS per wave and round: which stripe the record describes, how many supersteps of it are complete (carry
+            // written and visible), where its output begins, and -- once it is finished -- where it ends.  A wave waits only
+            // for the carry blocks it is about to load (kNeed supersteps ahead of its own) and never for a wave below it, so
+            // the chain of stripes cannot dead-lock; every wait is bounded all the same (a stuck team poisons its results
+            // instead of hanging the device).  No barrier inside the sweep.
+            constexpr uint32_t kUnknown = 0xFFFFFFFFu;
+            constexpr uint32_t kNeed = G == 64 ? 5u : 4u;  // block b of a stripe is complete once superstep b + 2 (G = 64) / b + 1 is done
+            auto rec_of = [&](uint32_t round, uint32_t w) { return team_rec + ((round & 1u) * WP + w) * 4u; };
+            auto ld = [&](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+            auto st = [&](uint32_t *p, uint32_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+            bool stuck = false;
+            auto wait_for = [&](auto &&ready) {
+                uint32_t spins = 0;
+                while (!stuck && !ready()) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 22)) {  // seconds: never reached unless the protocol is broken
+                        stuck = true;
+                        break;
+                    }
+                }
+            };
+            for (uint32_t round = 0; round * WP + uwave < max_stripes; ++round) {
+                const uint32_t v = round * WP + uwave;
+                stripe_setup(v);
+                const bool whole_row = __ballot(first && Tg != 0) != 0;
+                const uint32_t *prec = v > 0 ? rec_of(uwave == 0 ? round - 1 : round, (uwave + WP - 1) % WP) : nullptr;
+                uint32_t *mrec = rec_of(round, uwave);
+                uint32_t c_first = 0, in_last = kUnknown;
+                bool prod_done = v == 0;
+                if (v > 0) {
+                    wait_for([&] { return ld(prec) == v; });  // the wave above has begun stripe v - 1
+                    if (!whole_row) {
+                        wait_for([&] { return ld(prec + 2) != kUnknown || ld(prec + 3) != kUnknown; });
+                        const uint32_t f = ld(prec + 2);
+                        c_first = f == kUnknown ? Bs : min(f, Bs - 1u);  // nothing came out of the stripe above: nothing to do here
+                    }
+                }
+                carry_last_blk = kUnknown;
+                if (lane == 0) {
+                    st(mrec + 1, c_first);
+                    st(mrec + 2, kUnknown);
+                    st(mrec + 3, kUnknown);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    st(mrec, v + 1);
+                }
+                uint32_t out_first = kUnknown, out_last = 0;
+                for (uint32_t c = c_first; c < Bs; ++c) {
+                    if (!prod_done) {
+                        const uint32_t need = c + kNeed;
+                        wait_for([&] { return ld(prec + 1) >= need || ld(prec + 3) != kUnknown; });
+                        const uint32_t d = ld(prec + 3);
+                        if (d != kUnknown) {  // the stripe above is finished: behind block d it wrote nothing (zeros)
+                            prod_done = true;
+                            in_last = d;
+                            carry_last_blk = d;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    const bool skipped = superstep(v, c, c_first);
+                    if (!skipped) {
+                        if (out_first == kUnknown) {
+                            out_first = c;
+                            if (lane == 0) st(mrec + 2, c);  // see the one-wave loop: nothing before carry block c
+                        }
+                        out_last = c;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this superstep's carry columns before the count
+                    if (lane == 0) st(mrec + 1, c + 1u);
+                    if (skipped && !whole_row && prod_done && c > in_last + 2u) break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) st(mrec + 3, out_first == kUnknown ? 0u : team_last_block<G>(out_last));
+                if (v + 1 == max_stripes) {
+                    if (stuck) sumM = sumM / static_cast<T>(0) - sumM / static_cast<T>(0);  // NaN: never silently wrong
+                    write_result();
+                }
+            }
+            (void)n_super;
         }
     }
 }
