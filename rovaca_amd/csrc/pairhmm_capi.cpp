@@ -186,7 +186,8 @@ static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t m
     }
     const uint32_t per_wave = 64u / (uint32_t)sh.lanes;
     const uint32_t batches = (n_pairs + per_wave - 1) / per_wave;
-    const uint32_t stripes = (max_read + sh.lanes * rows_per_lane - 1) / (sh.lanes * rows_per_lane);
+    // teams of several waves run the band kernel, whose stripes are kBandRows rows per lane tall whatever the one-wave shape is
+    const uint32_t stripes = (max_read + sh.lanes * phmm::kBandRows - 1) / (sh.lanes * phmm::kBandRows);
     const uint32_t supersteps = (max_hap + (uint32_t)sh.lanes - 1 + 31) / 32;
     const uint32_t lag = sh.lanes == 64 ? 6u : 4u;  // team_lag<G>() of the kernel
     // (one pair per wave: since all-zero supersteps are skipped only one or two waves of a team have work at any time, and
@@ -1106,6 +1107,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
                 p.sh = cand;
             }
         }
+        // (teams of several waves run the band kernel at kBandRows rows per lane whatever p.rows says: launch_striped_f64)
         const uint32_t per_wave = 64u / (uint32_t)p.sh.lanes;
         p.teams = std::min<uint32_t>((p.cap + per_wave - 1) / per_wave, kRescueMaxTeams / p.sh.waves);
         p.carry_at = carry_total;

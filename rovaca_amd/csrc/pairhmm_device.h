@@ -19,6 +19,9 @@ constexpr int kStripedRowsF32 = PHMM_STRIPED_ROWS_F32;   // rows per lane of the
 // rows per lane of the striped fp64 kernel: instantiated for 4, 5 and 6 (stripes of 64, 80, 96 read rows with 16 lanes per
 // pair); the launch picks the one that wastes the fewest padding rows on the batch's read lengths
 constexpr int kStripedRowsF64Min = 4, kStripedRowsF64Max = 6;
+// rows per lane of the band kernel (teams of several waves, fp32 and fp64 alike): measured on config 5, fp32 pass 4.7 ms at 8
+// rows, 3.6 at 6, 2.7 at 4; fp64 re-run 2 520 / 2 740 / 2 760 GCUPS overall at 6 / 5 / 4
+constexpr int kBandRows = 4;
 constexpr int kStripedGroupsPerBlock = 4;  // a team (1, 4 or 8 waves) of the striped kernel sweeps four pairs
 
 // 32-bit words per haplotype match plane (column j, 1-based, is bit 31-((j-1)&31) of word (j-1)>>5); one spare
@@ -63,9 +66,9 @@ hipError_t launch_striped_f64(int rows_per_lane, bool uniform_gcp, int waves_per
 inline size_t team_lds_bytes(uint32_t plane_words_per_group, int waves_per_team, size_t value_bytes, int lanes_per_pair)
 {
     const size_t groups = 64u / (size_t)lanes_per_pair;
-    // planes of the team's pairs, one carry ring per (wave, group), and the waves' progress records (2 rounds x waves x 4 words)
+    // planes of the team's pairs, one carry ring per (wave, group), and the waves' progress records (2 rounds x waves x 8 words)
     return groups * (size_t)plane_words_per_group * sizeof(uint32_t) + (size_t)waves_per_team * groups * 3u * 64u * value_bytes +
-           2u * (size_t)waves_per_team * 4u * sizeof(uint32_t);
+           2u * (size_t)waves_per_team * 8u * sizeof(uint32_t);
 }
 inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t carry_stride, int lanes_per_pair)
 {

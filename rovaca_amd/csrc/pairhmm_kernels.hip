@@ -390,20 +390,10 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
 // supersteps between consecutive stripes of a pair.  The consumer reads three blocks (96 columns) ahead of its first step and
 // the producer's last lane trails its first by G - 1 columns, so 32 * lag >= 95 + G: 4 for 16-lane arrays, 5 (we take 6) for 64.
 template <int G> constexpr uint32_t team_lag() { return G == 64 ? 6u : 4u; }
-// the last carry block a stripe can have put anything into when its last non-skipped superstep was l: the last lane ends that
-// superstep at column 32 l + 32 - (G - 1)
-template <int G> __device__ __forceinline__ uint32_t team_last_block(uint32_t l) { return G == 64 ? (l > 0 ? l - 1u : 0u) : l; }
 
 // G = lanes per pair: 16 (four pairs per wave, DPP row_shr) or 64 (one pair per wave, DPP wave_shr -- for batches with
 // so few pairs that four-per-wave would leave the chip empty: one long-read pair then keeps up to WP waves busy)
 template <typename T, int K, bool UG, int WP, int G>
-#ifndef PHMM_TEAM_ROW_BARRIER_F32
-#define PHMM_TEAM_ROW_BARRIER_F32 1
-#endif
-#ifndef PHMM_TEAM_ROW_BARRIER_F64
-#define PHMM_TEAM_ROW_BARRIER_F64 0
-#endif
-#define PHMM_TEAM_ROW_BARRIER(T) (sizeof(T) == 4 ? PHMM_TEAM_ROW_BARRIER_F32 : PHMM_TEAM_ROW_BARRIER_F64)
 #ifndef PHMM_TEAM_WAVES_F32
 #define PHMM_TEAM_WAVES_F32 4
 #endif
@@ -427,8 +417,401 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
     const uint32_t plane_words = a.lds_words_per_group;
     uint32_t *pl = lds + grp * plane_words;
     T *ring = reinterpret_cast<T *>(lds + kGroups * plane_words) + (static_cast<size_t>(wave) * kGroups + grp) * 3u * kRing;
-    // progress records of the team's waves (several waves per team only): [round parity][wave][stripe + 1, supersteps done,
-    // first superstep with output - 1, last superstep with output - 1 once the stripe is finished]
+    // carry rows: one slab per (team, wave), laid out [column][group][M, X, Y] so that the slab base is wave-uniform (an
+    // SGPR pair) and lane 15 writes its three values with one store; stripe v reads the slab of the wave that ran v - 1
+    const uint32_t uwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    const uint32_t prev_wave = (uwave + WP - 1) % WP;
+    T *wbase = carry + (static_cast<size_t>(team) * WP + uwave) * 3u * kGroups * carry_stride;
+    const T *rbase = carry + (static_cast<size_t>(team) * WP + prev_wave) * 3u * kGroups * carry_stride;
+    const uint32_t n_pairs = a.n_pairs_dev ? *a.n_pairs_dev : a.n_pairs;  // uniform over the grid
+    const uint32_t quads = (n_pairs + kGroups - 1) / kGroups;  // pairs are taken kGroups at a time
+    const uint32_t iters = (quads + n_teams - 1) / n_teams;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t gidx = (it * n_teams + team) * kGroups + grp;
+        const bool valid = gidx < n_pairs;
+        const uint32_t pair = a.order[valid ? gidx : 0];
+        const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
+        const uint32_t R = a.read_len[r], H = a.hap_len[h];
+        const uint32_t roff = a.read_off[r];
+        const uint32_t W = planes_words(H);
+        __syncthreads();  // the previous quad's planes are no longer read
+        {
+            const uint32_t *src = a.planes + a.plane_off[h];
+            for (uint32_t i = lane + G * wave; i < kPlanes * W; i += G * WP) pl[i] = src[i];
+        }
+        const T init_y = Num<T>::init_const() / static_cast<T>(H);
+        const uint32_t n_stripes = valid ? (R + S - 1) / S : 0;
+        const int pad = static_cast<int>(n_stripes) * S - static_cast<int>(R);
+        uint32_t max_stripes = n_stripes;  // team-uniform; a pair with fewer stripes joins late so that all end together
+        if (kGroups > 1) {
+            max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 16));
+            max_stripes = max(max_stripes, (uint32_t)__shfl_xor((int)max_stripes, 32));
+        }
+        max_stripes = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_stripes);
+        const uint32_t Tpair = valid ? H + (G - 1) : 0;
+        uint32_t Tmax = Tpair;
+        if (kGroups > 1) {
+            Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+            Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+        }
+        Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
+        // Supersteps per stripe.  With several waves the stripes of a pair chase each other around the team: wave 0 starts
+        // its next stripe Bs supersteps after the previous one, and that stripe reads the carry of the one wave WP-1 is still
+        // sweeping, which started kLag * (WP - 1) supersteps after wave 0 did.  A haplotype shorter than kLag * WP * 32
+        // columns (the team shape is chosen for the longest of the launch) gets idle supersteps, or the carry would be read
+        // before it is written.
+        const uint32_t Bs = max((Tmax + 31u) / 32u, WP > 1 ? kLag * (uint32_t)WP : 1u);
+        const uint32_t n_rounds = (max_stripes + WP - 1) / WP;  // stripes per wave
+        const uint32_t n_super = n_rounds * Bs + kLag * (WP - 1);  // supersteps of this batch of pairs
+        const uint32_t wmax = W - 2;
+        __syncthreads();  // planes staged
+
+        // per-stripe state (lives in registers across supersteps)
+        Rows<T, K, UG> P;
+        T M[K], X[K], Y[K];
+        uint32_t mask[K];
+        uint32_t cls_lo = 0, cls_hi = 0;
+        T aM = 0, aX = 0, aY = 0, bM = 0, bX = 0, bY = 0;
+        T preM[2], preX[2], preY[2];
+        bool park_nz[2] = {true, true};  // does the parked carry block (ring half) hold anything but zeros
+        T curM = 0, curX = 0, curY = 0;  // the row above lane 0 at the next step's column (prefetched from the ring)
+        T sumM = 0, sumX = 0;
+        uint32_t Tg = 0;
+        bool first = false, last = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            M[k] = 0;
+            X[k] = 0;
+            Y[k] = 0;
+            mask[k] = 0;
+            P.p_mm[k] = 0;
+            P.p_mx[k] = 0;
+            P.p_yy[k] = 0;
+            P.lo[k] = 0;
+            P.hi[k] = 0;
+            if (!UG) {
+                P.p_my_r[UG ? 0 : k] = 0;
+                P.p_gapm_r[UG ? 0 : k] = 0;
+                P.p_xx_r[UG ? 0 : k] = 0;
+            }
+        }
+        if (UG) {
+            P.p_gapm_r[0] = 0;
+            P.p_xx_r[0] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            preM[q] = 0;
+            preX[q] = 0;
+            preY[q] = 0;
+        }
+
+        auto carry_load = [&](uint32_t blk) {  // columns 32 * blk + 1 + lane (+ 16) of the producer's row
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint32_t j = 32u * blk + 1u + (lane & 15u) + 16u * q;  // G = 64: lanes 16..63 repeat lanes 0..15
+                j = j <= H ? j : H;
+                if (first) {
+                    preM[q] = 0;
+                    preX[q] = 0;
+                    preY[q] = init_y;
+                }
+                else {
+                    const T *src = rbase + (j * kGroups + grp) * 3u;
+                    preM[q] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    preX[q] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    preY[q] = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        auto carry_park = [&](uint32_t blk) {
+            const uint32_t base = (blk & 1u) * 32u + (lane & 15u);
+            bool nz = false;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ring[base + 16 * q] = preM[q];
+                ring[kRing + base + 16 * q] = preX[q];
+                ring[2 * kRing + base + 16 * q] = preY[q];
+                nz = nz || preM[q] != 0 || preX[q] != 0 || preY[q] != 0;
+            }
+            park_nz[blk & 1u] = nz;  // this lane's share of the block; the groups' lanes are combined when the block is consumed
+        };
+        T nxtM = 0, nxtX = 0, nxtY = 0;
+        auto ring_fetch = [&](uint32_t t) {  // column t -> the "next" registers (issued a whole step before they are used)
+            const uint32_t e = (t - 1) & (kRing - 1);
+            nxtM = ring[e];
+            nxtX = ring[kRing + e];
+            nxtY = ring[2 * kRing + e];
+        };
+        auto masks_reload = [&](uint32_t t) {
+            const uint32_t jn = t > lane ? t - lane : 1u;
+            uint32_t w = (jn - 1) >> 5;
+            const uint32_t sh = (jn - 1) & 31u;
+            w = w < wmax ? w : wmax;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
+                const uint32_t *p = pl + cls * W + w;
+                const uint32_t w0 = p[0], w1 = p[1];
+                mask[k] = (w0 << sh) | ((w1 >> 1) >> (31u - sh));
+            }
+        };
+        auto stripe_setup = [&](uint32_t v) {
+            const bool in_play = v + n_stripes >= max_stripes;
+            const uint32_t stripe = in_play ? v + n_stripes - max_stripes : 0;  // this pair's own stripe index
+            first = stripe == 0;
+            last = stripe + 1 == n_stripes;
+            const bool live = valid && in_play;
+            Tg = live ? Tpair : 0;
+            cls_lo = 0;
+            cls_hi = 0;
+            if (UG) {
+                uint32_t c0 = a.read_gcp[roff] & 127u;
+                P.p_gapm_r[0] = static_cast<T>(1.0) - ph2pr[c0];
+                P.p_xx_r[0] = ph2pr[c0];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int row = static_cast<int>(stripe) * S + static_cast<int>(lane) * K + k - pad;
+                uint32_t cls = 5;
+                if (live && row >= 0) {
+                    const uint32_t at = roff + static_cast<uint32_t>(row);
+                    const uint32_t _i = a.read_ins[at] & 127u, _d = a.read_del[at] & 127u, _c = a.read_gcp[at] & 127u,
+                                   _q = a.read_qual[at] & 127u;
+                    const uint32_t mx = _i > _d ? _i : _d, mn = _i > _d ? _d : _i;
+                    P.p_mm[k] = mmtab[((mx * (mx + 1)) >> 1) + mn];
+                    P.p_mx[k] = ph2pr[_i];
+                    if (!UG) P.p_my_r[UG ? 0 : k] = ph2pr[_d];
+                    P.p_yy[k] = ph2pr[_c];
+                    if (!UG) {
+                        P.p_gapm_r[UG ? 0 : k] = static_cast<T>(1.0) - ph2pr[_c];
+                        P.p_xx_r[UG ? 0 : k] = ph2pr[_c];
+                    }
+                    const T dist = ph2pr[_q];
+                    P.hi[k] = static_cast<T>(1.0) - dist;
+                    P.lo[k] = Num<T>::div3(dist);
+                    cls = read_class(a.read_bases[at]);
+                    M[k] = 0;
+                    X[k] = 0;
+                    Y[k] = 0;
+                }
+                else {
+                    P.p_mm[k] = 0;
+                    P.p_mx[k] = 0;
+                    if (!UG) P.p_my_r[UG ? 0 : k] = 0;
+                    P.p_yy[k] = 1;
+                    if (!UG) {
+                        P.p_gapm_r[UG ? 0 : k] = 0;
+                        P.p_xx_r[UG ? 0 : k] = 0;
+                    }
+                    P.hi[k] = 0;
+                    P.lo[k] = 0;
+                    M[k] = 0;
+                    X[k] = 0;
+                    Y[k] = init_y;
+                }
+                if (k < 10)
+                    cls_lo |= cls << (3 * k);
+                else
+                    cls_hi |= cls << (3 * (k - 10));
+            }
+            // column 0 of the row above slot 0: init for the boundary row and its replicas (stripe 0 only), else 0
+            const T y_col0 = (first && static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
+            aM = 0;
+            aX = 0;
+            aY = y_col0;
+            bM = 0;
+            bX = 0;
+            bY = y_col0;
+            if (first) {
+                sumM = 0;
+                sumX = 0;
+            }
+            // carry ring: blocks 0 and 1 parked, block 2 in flight
+            carry_load(0);
+            carry_park(0);
+            carry_load(1);
+            carry_park(1);
+            carry_load(2);
+            ring_fetch(1);
+            curM = nxtM;
+            curX = nxtX;
+            curY = nxtY;
+        };
+        auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0, auto is_last) {
+            // lane 0 keeps `old` = the row above at column t (boundary row or carry); lanes 1..15 take lane-1's last row
+            uM0 = dpp_shr1<G>(curM, M[K - 1]);
+            uX0 = dpp_shr1<G>(curX, X[K - 1]);
+            uY0 = dpp_shr1<G>(curY, Y[K - 1]);
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                uint32_t nm;
+                const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
+                mask[k] = nm;
+                const T prior = hit ? P.hi[k] : P.lo[k];
+                Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my(k));
+                const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
+                T tt = gM * P.p_mm[k];
+                tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
+                tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
+                M[k] = tt * prior;
+                __builtin_amdgcn_sched_barrier(0);  // rows in program order, as in the single-pass kernel
+            }
+            T uM = uM0, uX = uX0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                X[k] = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
+                uM = M[k];
+                uX = X[k];
+            }
+            if (is_last) {
+                sumM = sumM + M[K - 1];
+                sumX = sumX + X[K - 1];
+            }
+            else if (lane == G - 1) {
+                const uint32_t j = t - (G - 1);  // the last lane is at column t - (G-1) >= 1 whenever it is active
+                struct V3
+                {
+                    T m, x, y;
+                };
+                *reinterpret_cast<V3 *>(wbase + (j * kGroups + grp) * 3u) = V3{M[K - 1], X[K - 1], Y[K - 1]};
+            }
+        };
+        // 32 steps with every lane of the wave busy: no per-lane predicate, the two register sets swap roles without a move
+        auto superstep_full = [&](uint32_t t0, auto is_last) {
+#pragma unroll 1
+            for (uint32_t t = t0; t < t0 + 32u; t += 2) {
+                ring_fetch(t + 1);
+                step(t, aM, aX, aY, bM, bX, bY, is_last);
+                curM = nxtM;
+                curX = nxtX;
+                curY = nxtY;
+                ring_fetch(t + 2);
+                step(t + 1, bM, bX, bY, aM, aX, aY, is_last);
+                curM = nxtM;
+                curX = nxtX;
+                curY = nxtY;
+            }
+        };
+
+        for (uint32_t g = 0; g < n_super; ++g) {
+            const int32_t tau = static_cast<int32_t>(g) - static_cast<int32_t>(kLag * wave);
+            if (tau >= 0 && static_cast<uint32_t>(tau) < n_rounds * Bs) {
+                const uint32_t round = static_cast<uint32_t>(tau) / Bs, c = static_cast<uint32_t>(tau) % Bs;
+                const uint32_t v = round * WP + wave;
+                if (v < max_stripes) {
+                    if (c == 0) {
+                        stripe_setup(v);
+                    }
+                    else {
+                        carry_park(c + 1);  // block c + 1 joins the ring (block c was parked one superstep ago)
+                        carry_load(c + 2);
+                    }
+                    const uint32_t t0 = 32u * c + 1u;
+                    const uint32_t t1 = min(t0 + 31u, Tmax);
+                    uint32_t Tmin = Tg;  // wave-uniform: the last step at which every group of the wave is still sweeping
+                    if (kGroups > 1) {
+                        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+                        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
+                    }
+                    Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
+                    // A superstep with nothing but zeros going in -- the carry block it consumes and every value the wave
+                    // holds -- puts nothing but zeros out (each value is a sum of non-negative products of its neighbours,
+                    // and fp32 runs flush-to-zero): write the zero carry columns and move on.  This is where long reads
+                    // spend most of their fp32 pass: a 10-kbp read underflows for good after some 2 000 rows.
+                    bool lane_nz = park_nz[c & 1u] || aM != 0 || aX != 0 || aY != 0 || bM != 0 || bX != 0 || bY != 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) lane_nz = lane_nz || M[k] != 0 || X[k] != 0 || Y[k] != 0;
+                    if (__ballot(lane_nz && Tg != 0) == 0 && !a.no_early_exit) {
+                        if (Tg != 0 && v + 1 != max_stripes) {
+                            struct V3
+                            {
+                                T m, x, y;
+                            };
+                            for (uint32_t t = t0 + lane; t <= t1 && t <= Tg; t += G) {
+                                if (t > (uint32_t)(G - 1)) *reinterpret_cast<V3 *>(wbase + ((t - (G - 1)) * kGroups + grp) * 3u) = V3{0, 0, 0};
+                            }
+                        }
+                        ring_fetch(t1 + 1);
+                        curM = nxtM;
+                        curX = nxtX;
+                        curY = nxtY;
+                    }
+                    else {
+                        masks_reload(t0);
+                        if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
+                            // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
+                            if (v + 1 == max_stripes)
+                                superstep_full(t0, std::true_type{});
+                            else
+                                superstep_full(t0, std::false_type{});
+                        }
+                        else {
+                            for (uint32_t t = t0; t <= t1; ++t) {
+                                ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
+                                if ((t > lane) && (t <= Tg)) {
+                                    if (t & 1u)
+                                        step(t, aM, aX, aY, bM, bX, bY, last);
+                                    else
+                                        step(t, bM, bX, bY, aM, aX, aY, last);
+                                }
+                                curM = nxtM;
+                                curX = nxtX;
+                                curY = nxtY;
+                            }
+                        }
+                    }
+                    if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == G - 1) {
+                        const T res = sumM + sumX;
+                        reinterpret_cast<T *>(a.out_raw)[pair] = res;
+                        if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))
+                            a.rescue_list[atomicAdd(a.rescue_count, 1u)] = pair;
+                    }
+                }
+            }
+            __syncthreads();  // carry columns written in this superstep are visible to the team before the next one
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// the band kernel: teams of SEVERAL waves for few, long pairs (BASELINE config 5).  Same stripes, same carry rows, same cell
+// update as the team kernel above -- what differs is how the waves of a team are driven.  A long read against a long haplotype
+// is a serial walk of the alignment band down the stripes: a batch of a thousand such pairs puts one or two busy waves on a
+// SIMD, and the pass takes as long as its longest pair.  So (1) the waves of a team run at their own pace, synchronised
+// through four words of LDS per wave instead of a barrier per superstep, and (2) a stripe sweeps only its band: it starts at the
+// first carry block the stripe above put anything into and stops when that stripe is finished and the state is zero again.
+// ----------------------------------------------------------------------------------------------------
+// the last carry block a stripe can have put anything into when its last non-skipped superstep was l: the last lane ends that
+// superstep at column 32 l + 32 - (G - 1)
+template <int G> __device__ __forceinline__ uint32_t team_last_block(uint32_t l) { return G == 64 ? (l > 0 ? l - 1u : 0u) : l; }
+
+// Rows in program order (a scheduling barrier after each row, as in the single-pass and team kernels) pay in the issue-bound regime,
+// several waves per SIMD.  Here a wave or two share a SIMD and each row's dependent mul/fma chain sets the pace: the kernel runs
+// faster when the compiler may interleave the rows (config 5: fp32 pass 6.6 -> 5.3 ms).
+#ifndef PHMM_BAND_ROW_BARRIER
+#define PHMM_BAND_ROW_BARRIER 0
+#endif
+template <typename T, int K, bool UG, int WP, int G>
+__global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 : PHMM_TEAM_WAVES_F64) pairhmm_band_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
+{
+    extern __shared__ uint32_t lds[];
+    constexpr int S = G * K;
+    constexpr uint32_t kGroups = 64 / G;  // pairs per wave
+    constexpr uint32_t kRing = 64;        // columns parked per value: two blocks of 32
+    constexpr uint32_t kLag = team_lag<G>();
+    const uint32_t lane = threadIdx.x & (G - 1);
+    const uint32_t grp = (threadIdx.x & 63u) / G;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t team = blockIdx.x, n_teams = gridDim.x;
+    const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
+    const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
+    // LDS: [kGroups][planes] shared by the team, then [WP waves][kGroups][3 values][kRing] carry ring
+    const uint32_t plane_words = a.lds_words_per_group;
+    uint32_t *pl = lds + grp * plane_words;
+    T *ring = reinterpret_cast<T *>(lds + kGroups * plane_words) + (static_cast<size_t>(wave) * kGroups + grp) * 3u * kRing;
+    // progress records of the team's waves: [round parity][wave][stripe + 1, supersteps done, first carry block with output, last
+    // carry block with output (once the stripe is finished), superstep the sweep began at, 3 spare words]
     uint32_t *team_rec = reinterpret_cast<uint32_t *>(reinterpret_cast<T *>(lds + kGroups * plane_words) + static_cast<size_t>(WP) * kGroups * 3u * kRing);
     // carry rows: one slab per (team, wave), laid out [column][group][M, X, Y] so that the slab base is wave-uniform (an
     // SGPR pair) and lane 15 writes its three values with one store; stripe v reads the slab of the wave that ran v - 1
@@ -452,7 +835,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             const uint32_t *src = a.planes + a.plane_off[h];
             for (uint32_t i = lane + G * wave; i < kPlanes * W; i += G * WP) pl[i] = src[i];
         }
-        if (WP > 1 && threadIdx.x < 2u * WP * 4u) team_rec[threadIdx.x] = 0;  // no wave has begun any stripe of these pairs
+        if (WP > 1 && threadIdx.x < 2u * WP * 8u) team_rec[threadIdx.x] = 0;  // no wave has begun any stripe of these pairs
         const T init_y = Num<T>::init_const() / static_cast<T>(H);
         const uint32_t n_stripes = valid ? (R + S - 1) / S : 0;
         const int pad = static_cast<int>(n_stripes) * S - static_cast<int>(R);
@@ -521,6 +904,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
         }
 
         uint32_t carry_last_blk = 0xFFFFFFFFu;  // the producer stripe wrote nothing (i.e. zeros) behind this block; unknown: all ones
+        uint32_t carry_first_blk = 0;           // ... and nothing at all, not even zeros, before this one (it began its sweep there)
         auto carry_load = [&](uint32_t blk) {  // columns 32 * blk + 1 + lane (+ 16) of the producer's row
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -531,7 +915,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     preX[q] = 0;
                     preY[q] = init_y;
                 }
-                else if (blk > carry_last_blk) {
+                else if (blk > carry_last_blk || blk < carry_first_blk) {
                     preM[q] = 0;
                     preX[q] = 0;
                     preY[q] = 0;
@@ -677,10 +1061,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
                 tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
                 M[k] = tt * prior;
-                // fp32: rows in program order, as in the single-pass kernel (four waves per SIMD, issue-bound).  fp64 re-runs and
-                // long reads are the opposite regime -- one or two waves per SIMD, bound by the latency of each row's dependent
-                // mul/fma chain -- so there the compiler may interleave the rows.
-                if (PHMM_TEAM_ROW_BARRIER(T)) __builtin_amdgcn_sched_barrier(0);
+                if (PHMM_BAND_ROW_BARRIER) __builtin_amdgcn_sched_barrier(0);  // rows in program order: see the macro
             }
             T uM = uM0, uX = uX0;
 #pragma unroll
@@ -795,63 +1176,13 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             }
         };
 
-        if constexpr (WP == 1) {
-            // One wave, all stripes of its pairs one after the other -- and only the BAND of each.  Below the first stripe of a
-            // pair everything is exactly zero until the first non-zero column of the carry arrives from the stripe above, and
-            // again once the band has passed; the wave remembers between which supersteps the stripe it has just finished
-            // produced anything (wave-uniform: the union over the wave's pairs) and starts the next stripe right there instead
-            // of walking -- superstep by superstep, a barrier, a prefetch and a ballot each -- through thousands of zero columns.
-            // Columns behind the band are never written: the consumer is told where they begin (carry_last_blk).  Same bits:
-            // what is not computed is zero, and zero columns add +0 to the sums.
-            uint32_t in_first = 0, in_last = 0xFFFFFFFFu;  // carry blocks the stripe done before this one put anything into: first, last
-            for (uint32_t v = 0; v < max_stripes; ++v) {
-                stripe_setup(v);
-                // a pair's own first stripe has the boundary row above it: non-zero at every column
-                const bool whole_row = a.no_early_exit || __ballot(first && Tg != 0) != 0;
-                const uint32_t c_first = whole_row ? 0u : min(in_first, Bs - 1u);
-                carry_last_blk = whole_row ? 0xFFFFFFFFu : in_last;
-                uint32_t out_first = 0xFFFFFFFFu, out_last = 0;
-                for (uint32_t c = c_first; c < Bs; ++c) {
-                    const bool skipped = superstep(v, c, c_first);
-                    if (!skipped) {
-                        if (out_first == 0xFFFFFFFFu) out_first = c;
-                        out_last = c;
-                    }
-                    else if (!whole_row && c > in_last + 2u) {
-                        break;  // no carry will come any more and the state is zero: the rest of the stripe is zero
-                    }
-                }
-                // Where this stripe's output is non-zero, in carry blocks.  The first non-skipped superstep f was entered with an
-                // all-zero state, so what made it non-zero is carry block f, which lane 0 meets at column 32 f + 1 at the earliest
-                // and the last lane, G - 1 steps later, at that same column: nothing before block f.  The last non-skipped
-                // superstep l leaves the last lane at column 32 l + 32 - (G - 1): block l (G = 16) or l - 1 (G = 64); that block is
-                // complete once superstep l + 1 has run -- it has, the loop leaves only after a skipped superstep or at the end
-                // of the row.  Blocks outside [first, last] are never read by the next stripe (some of them were never written).
-                in_first = out_first == 0xFFFFFFFFu ? Bs : out_first;  // nothing at all: the next stripe has nothing to do either
-                in_last = out_first == 0xFFFFFFFFu ? 0u : team_last_block<G>(out_last);
-                if (v + 1 == max_stripes) write_result();
-                __syncthreads();  // (one wave) the carry written by this stripe is read by the next one
-            }
-        }
-        else if (a.no_early_exit) {
-            // test hook (PHMM_NO_EARLY_EXIT): the plain lock-step pipeline -- every superstep of every stripe, a barrier each
-            for (uint32_t g = 0; g < n_super; ++g) {
-                const int32_t tau = static_cast<int32_t>(g) - static_cast<int32_t>(kLag * wave);
-                if (tau >= 0 && static_cast<uint32_t>(tau) < n_rounds * Bs) {
-                    const uint32_t round = static_cast<uint32_t>(tau) / Bs, c = static_cast<uint32_t>(tau) % Bs;
-                    const uint32_t v = round * WP + wave;
-                    if (v < max_stripes) {
-                        if (c == 0) stripe_setup(v);
-                        superstep(v, c, 0u);
-                        if (c + 1 == Bs && v + 1 == max_stripes) write_result();
-                    }
-                }
-                __syncthreads();  // carry columns written in this superstep are visible to the team before the next one
-            }
-        }
-        else {
-            // Several waves per team, each at its own pace.  Wave w sweeps the stripes w, w + WP, ... and, as in the one-wave
-            // loop above, only the band of each.  What it needs from the wave above (stripe v - 1) travels through four words
+        {
+            // Several waves per team (few, long pairs: a wave or two per SIMD, latency-bound), each at its own pace.  Wave w sweeps
+            // the stripes w, w + WP, ... and only the BAND of each: below the first stripe of a pair everything is exactly zero
+            // until the first non-zero column of the carry arrives from the stripe above, and again once the band has passed, so
+            // a stripe starts at the first carry block the stripe above put anything into and stops once that stripe is finished,
+            // its last such block is consumed and the state is zero again.  Columns outside are never computed (they are zero,
+            // and zero columns add +0 to the sums) and never written: the consumer is told where they end.  What it needs from the wave above (stripe v - 1) travels through four words
             // of LDS per wave and round: which stripe the record describes, how many supersteps of it are complete (carry
             // written and visible), where its output begins, and -- once it is finished -- where it ends.  A wave waits only
             // for the carry blocks it is about to load (kNeed supersteps ahead of its own) and never for a wave below it, so
@@ -859,7 +1190,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             // instead of hanging the device).  No barrier inside the sweep.
             constexpr uint32_t kUnknown = 0xFFFFFFFFu;
             constexpr uint32_t kNeed = G == 64 ? 5u : 4u;  // block b of a stripe is complete once superstep b + 2 (G = 64) / b + 1 is done
-            auto rec_of = [&](uint32_t round, uint32_t w) { return team_rec + ((round & 1u) * WP + w) * 4u; };
+            auto rec_of = [&](uint32_t round, uint32_t w) { return team_rec + ((round & 1u) * WP + w) * 8u; };
             auto ld = [&](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
             auto st = [&](uint32_t *p, uint32_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
             bool stuck = false;
@@ -876,7 +1207,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             for (uint32_t round = 0; round * WP + uwave < max_stripes; ++round) {
                 const uint32_t v = round * WP + uwave;
                 stripe_setup(v);
-                const bool whole_row = __ballot(first && Tg != 0) != 0;
+                const bool whole_row = a.no_early_exit || __ballot(first && Tg != 0) != 0;  // (test hook: sweep everything)
                 const uint32_t *prec = v > 0 ? rec_of(uwave == 0 ? round - 1 : round, (uwave + WP - 1) % WP) : nullptr;
                 uint32_t *mrec = rec_of(round, uwave);
                 uint32_t c_first = 0, in_last = kUnknown;
@@ -890,7 +1221,12 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     }
                 }
                 carry_last_blk = kUnknown;
+                // A stripe that sweeps the whole row because one of the wave's pairs begins here still reads, for its other pairs,
+                // the carry of a stripe above that may have begun in the middle of the row: the blocks before that point were
+                // never written (they are zero).
+                carry_first_blk = v > 0 ? ld(prec + 4) : 0u;
                 if (lane == 0) {
+                    st(mrec + 4, c_first);
                     st(mrec + 1, c_first);
                     st(mrec + 2, kUnknown);
                     st(mrec + 3, kUnknown);
@@ -914,7 +1250,10 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     if (!skipped) {
                         if (out_first == kUnknown) {
                             out_first = c;
-                            if (lane == 0) st(mrec + 2, c);  // see the one-wave loop: nothing before carry block c
+                            // The first non-skipped superstep f was entered with an all-zero state, so what made it non-zero is
+                            // carry block f, which lane 0 meets at column 32 f + 1 at the earliest and the last lane, G - 1 steps
+                            // later, at that same column: nothing comes out before block f.
+                            if (lane == 0) st(mrec + 2, c);
                         }
                         out_last = c;
                     }
@@ -923,6 +1262,9 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     if (skipped && !whole_row && prod_done && c > in_last + 2u) break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                // The last non-skipped superstep l leaves the last lane at column 32 l + 32 - (G - 1): block l (G = 16) or l - 1
+                // (G = 64); that block is complete once superstep l + 1 has run -- it has, the loop leaves only after a skipped
+                // superstep or at the end of the row.
                 if (lane == 0) st(mrec + 3, out_first == kUnknown ? 0u : team_last_block<G>(out_last));
                 if (v + 1 == max_stripes) {
                     if (stuck) sumM = sumM / static_cast<T>(0) - sumM / static_cast<T>(0);  // NaN: never silently wrong
@@ -1053,55 +1395,58 @@ template <typename T, int K, bool UG, int WP, int G>
 static hipError_t launch_team_one(const KernelArgs &a, void *carry, uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
     const size_t shmem = team_lds_bytes(a.lds_words_per_group, WP, sizeof(T), G);
-    auto kern = pairhmm_team_kernel<T, K, UG, WP, G>;
-    if (shmem > 64u * 1024u) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(shmem));
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(teams), dim3(64 * WP), shmem, s, a, static_cast<T *>(carry), carry_stride);
-    return hipGetLastError();
+    // one wave per team: the lock-step team kernel; several: the band kernel (free-running waves, band-only sweeps)
+    auto launch = [&](auto kern) -> hipError_t {
+        if (shmem > 64u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(shmem));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(teams), dim3(64 * WP), shmem, s, a, static_cast<T *>(carry), carry_stride);
+        return hipGetLastError();
+    };
+    if constexpr (WP == 1)
+        return launch(pairhmm_team_kernel<T, K, UG, 1, G>);
+    else
+        return launch(pairhmm_band_kernel<T, K, UG, WP, G>);
 }
 
-template <typename T, int K, int G>
-static hipError_t launch_team_g(bool ug, int waves_per_team, const KernelArgs &a, void *carry, uint32_t carry_stride,
-                                uint32_t teams, hipStream_t s)
-{
-    if (waves_per_team == 8)
-        return ug ? launch_team_one<T, K, true, 8, G>(a, carry, carry_stride, teams, s)
-                  : launch_team_one<T, K, false, 8, G>(a, carry, carry_stride, teams, s);
-    if (waves_per_team == 4)
-        return ug ? launch_team_one<T, K, true, 4, G>(a, carry, carry_stride, teams, s)
-                  : launch_team_one<T, K, false, 4, G>(a, carry, carry_stride, teams, s);
-    if (waves_per_team == 1)
-        return ug ? launch_team_one<T, K, true, 1, G>(a, carry, carry_stride, teams, s)
-                  : launch_team_one<T, K, false, 1, G>(a, carry, carry_stride, teams, s);
-    return hipErrorInvalidValue;
-}
-
-template <typename T, int K>
-static hipError_t launch_team_t(bool ug, int waves_per_team, int lanes_per_pair, const KernelArgs &a, void *carry,
-                                uint32_t carry_stride, uint32_t teams, hipStream_t s)
+// one instantiation per (type, rows per lane, waves per team): one wave per team is the lock-step team kernel at the stripe
+// height tuned for throughput, several waves are the band kernel at kBandRows rows per lane (latency-bound: short steps win)
+template <typename T, int K, int WP>
+static hipError_t launch_team_w(bool ug, int lanes_per_pair, const KernelArgs &a, void *carry, uint32_t carry_stride, uint32_t teams,
+                                hipStream_t s)
 {
     if (a.n_pairs == 0 && !a.n_pairs_dev) return hipSuccess;
-    if (lanes_per_pair == 64) return launch_team_g<T, K, 64>(ug, waves_per_team, a, carry, carry_stride, teams, s);
-    if (lanes_per_pair == 16) return launch_team_g<T, K, 16>(ug, waves_per_team, a, carry, carry_stride, teams, s);
+    if (lanes_per_pair == 64)
+        return ug ? launch_team_one<T, K, true, WP, 64>(a, carry, carry_stride, teams, s)
+                  : launch_team_one<T, K, false, WP, 64>(a, carry, carry_stride, teams, s);
+    if (lanes_per_pair == 16)
+        return ug ? launch_team_one<T, K, true, WP, 16>(a, carry, carry_stride, teams, s)
+                  : launch_team_one<T, K, false, WP, 16>(a, carry, carry_stride, teams, s);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a, float *carry,
                               uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
-    return launch_team_t<float, kStripedRowsF32>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team == 1) return launch_team_w<float, kStripedRowsF32, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team == 4) return launch_team_w<float, kBandRows, 4>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team == 8) return launch_team_w<float, kBandRows, 8>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_striped_f64(int rows_per_lane, bool uniform_gcp, int waves_per_team, int lanes_per_pair, const KernelArgs &a,
                               double *carry, uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
     static_assert(kStripedRowsF64Min == 4 && kStripedRowsF64Max == 6, "instantiate every rows-per-lane value in the range");
-    if (rows_per_lane == 4) return launch_team_t<double, 4>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
-    if (rows_per_lane == 5) return launch_team_t<double, 5>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
-    if (rows_per_lane == 6) return launch_team_t<double, 6>(uniform_gcp, waves_per_team, lanes_per_pair, a, carry, carry_stride, teams, s);
+    // several waves per team: kBandRows rows per lane whatever was asked for (see launch_team_w)
+    if (waves_per_team == 4) return launch_team_w<double, kBandRows, 4>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team == 8) return launch_team_w<double, kBandRows, 8>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team != 1) return hipErrorInvalidValue;
+    if (rows_per_lane == 4) return launch_team_w<double, 4, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (rows_per_lane == 5) return launch_team_w<double, 5, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (rows_per_lane == 6) return launch_team_w<double, 6, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
     return hipErrorInvalidValue;
 }
 

@@ -358,3 +358,30 @@ def test_symbols_outside_ACGTN_never_match(engine):
     hb[idx] = rng.choice(odd, idx.size)
     b.read_bases, b.hap_bases = rb, hb
     _check_against_oracle(engine, b)
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+def test_band_kernel_pair_joining_late_beside_a_stripe_that_began_mid_row(engine, waves, monkeypatch):
+    # found by tests/debug/fuzz_gpu.py (seed 417): four pairs per wave with different stripe counts.  When a pair with fewer
+    # stripes begins (its boundary row is non-zero everywhere, so the wave sweeps the whole row), the wave's other pairs read the
+    # carry of a stripe above that may have begun its sweep in the middle of the row -- the blocks before that point were never
+    # written and must read as zero.  Reads that sit at the far end of a long haplotype put the band there; noisy reads make the
+    # true result underflow to exactly zero, so any stale value shows.
+    monkeypatch.setenv("PHMM_FORCE_TEAM_WAVES", str(waves))
+    monkeypatch.setenv("PHMM_FORCE_TEAM_LANES", "16")
+    rng = np.random.default_rng(417)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    haps = [acgt[rng.integers(0, 4, n)] for n in (3603, 3500, 2900, 3603)]
+    reads = []
+    for R, h, at_end, noise in ((1500, 0, True, 0.0), (796, 0, True, 0.3), (300, 1, False, 0.0), (1990, 3, True, 0.01), (520, 2, True, 0.3),
+                                (1400, 1, False, 0.02), (260, 3, True, 0.0), (1100, 2, True, 0.3)):
+        hap = haps[h]
+        a = len(hap) - R if at_end else int(rng.integers(0, len(hap) - R + 1))
+        seq = hap[a:a + R].copy()
+        bad = rng.random(R) < noise
+        seq[bad] = acgt[rng.integers(0, 4, int(bad.sum()))]
+        q = rng.integers(6, 41, R).astype(np.uint8)
+        g = np.full(R, 40, np.uint8)
+        reads.append((seq, q, g, g, np.full(R, 10, np.uint8)))
+    pairs = [(r, h) for r in range(len(reads)) for h in range(len(haps))]
+    _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))

@@ -1,8 +1,7 @@
 #!/bin/bash
-run() { timeout -k 5 150 python bench.py --config c5 --steps 4 --warmup 2 --no-cpu-baseline --no-e2e 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*\|"pass_kernel_ms": [0-9.]*' | tr '\n' ' '; echo; }
+# tuning aid: config 5 against alternative builds of the HIP library (rovaca_amd/lib/variants/lib_*.so)
+run() { timeout -k 5 150 python bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*\|"pass_kernel_ms": [0-9.]*' | tr '\n' ' '; echo; }
+echo "=== baseline"; run
 for v in rovaca_amd/lib/variants/lib_*.so; do
-  for w in 0 1; do
-    echo "=== $v waves_forced=$w"
-    if [ $w = 1 ]; then ROVACA_AMD_HIP_LIB=$PWD/$v PHMM_FORCE_TEAM_WAVES=1 run; else ROVACA_AMD_HIP_LIB=$PWD/$v run; fi
-  done
+  echo "=== $v"; ROVACA_AMD_HIP_LIB=$PWD/$v run
 done
