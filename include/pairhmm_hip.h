@@ -155,6 +155,8 @@ int phmm_multi_sweep_timed(phmm_multi *m, phmm_multi_resident *rb, int iters, do
 int phmm_multi_download(phmm_multi *m, phmm_multi_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats);
 int phmm_multi_shard_cells(const phmm_multi_resident *rb, uint64_t *cells /*[n_devices], nullable*/, uint64_t *pairs /*nullable*/);
 void phmm_multi_release(phmm_multi *m, phmm_multi_resident *rb);
+/* the cut alone (host only, no device): slice_of_pair[p] (nullable) = the slice pair p falls into, cells[g] (nullable) = its cells */
+int phmm_plan_slices(const phmm_batch *batch, int n_slices, uint32_t *slice_of_pair, uint64_t *cells);
 
 /* ---- allele marginalisation, the step right after the seam ----
  * One sample of AlleleLikelihoods::marginal_likelihoods_direct (genotype/allele_likelihoods.hpp:702-732), called from

@@ -20,7 +20,7 @@ EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy
            "phmm_get_tables", "phmm_download_read_table",
            "phmm_create_multi", "phmm_destroy_multi", "phmm_multi_device_count", "phmm_multi_device_id", "phmm_multi_compute",
            "phmm_multi_upload", "phmm_multi_sweep", "phmm_multi_synchronize", "phmm_multi_sweep_timed", "phmm_multi_download",
-           "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize", "phmm_create_cpu", "phmm_backend_name")
+           "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize", "phmm_create_cpu", "phmm_backend_name", "phmm_plan_slices")
 
 
 class PhmmBatch(C.Structure):
@@ -111,6 +111,8 @@ def lib():
     L.phmm_marginalize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                    C.POINTER(C.c_double)]
     L.phmm_marginalize.restype = C.c_int
+    L.phmm_plan_slices.argtypes = [C.POINTER(PhmmBatch), C.c_int, C.c_void_p, C.c_void_p]
+    L.phmm_plan_slices.restype = C.c_int
     L.phmm_create_cpu.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.phmm_create_cpu.restype = C.c_int
     L.phmm_backend_name.argtypes = [C.c_void_p]
@@ -262,6 +264,16 @@ class CpuEngine(Engine):
     @property
     def backend(self):
         return lib().phmm_backend_name(self.handle).decode()
+
+
+def plan_slices(batch, n, cross=False):
+    """The multi-device cut without a device: (slice index per pair, cells per slice)."""
+    cb = _c_batch(batch, cross)
+    n_pairs = batch.n_reads * batch.n_haps if cross else batch.n_pairs
+    which = np.zeros(n_pairs, np.uint32)
+    cells = np.zeros(n, np.uint64)
+    _check(lib().phmm_plan_slices(C.byref(cb), int(n), _ptr(which), _ptr(cells)), "phmm_plan_slices")
+    return which, cells
 
 
 class MultiResident:

@@ -2107,6 +2107,23 @@ int phmm_multi_download(phmm_multi *m, phmm_multi_resident *rb, float *raw, doub
 {
     return guarded("phmm_multi_download", [&] { return impl::phmm_multi_download(m, rb, raw, l10, st); });
 }
+int phmm_plan_slices(const phmm_batch *b, int n_slices, uint32_t *slice_of_pair, uint64_t *cells)
+{
+    // the cut alone, no device involved: lets the N > 1 path be checked on a machine without GPUs
+    return guarded("phmm_plan_slices", [&]() -> int {
+        if (!b || n_slices < 1) return fail(PHMM_E_INVALID, "phmm_plan_slices: bad arguments");
+        phmm_multi_resident plan;
+        const int rc = impl::partition_equal_cells(b, (size_t)n_slices, &plan);
+        if (rc != PHMM_OK) return rc;
+        for (int g = 0; g < n_slices; ++g) {
+            if (cells) cells[g] = plan.cells[g];
+            if (slice_of_pair)
+                for (uint32_t p : plan.index[g]) slice_of_pair[p] = (uint32_t)g;
+        }
+        return PHMM_OK;
+    });
+}
+
 int phmm_multi_shard_cells(const phmm_multi_resident *rb, uint64_t *cells, uint64_t *pairs)
 {
     if (!rb) return fail(PHMM_E_INVALID, "phmm_multi_shard_cells: null argument");

@@ -5,11 +5,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
 #include "../../oracle/phmm_oracle.h"
 #include "../../oracle/sw_oracle.h"
+#include "../../rovaca_amd/csrc/pairhmm_cpu.h"
 #include "../../rovaca_amd/host/pairhmm_host_logic.h"
 
 int main()
@@ -55,6 +57,72 @@ int main()
         for (auto &v : rl) v = 1 + (int32_t)(rng() % 250);
         rovaca_amd::normalize_likelihoods(lik.data(), nr, nh);
         checksum += rovaca_amd::poorly_modelled_reads(lik.data(), rl.data(), nr, nh).size();
+    }
+    // the CPU backend of the C ABI (rovaca_amd/csrc/pairhmm_cpu.cpp): scalar and AVX2 inter-pair kernels on small batches -- groups of
+    // equal shape fill vectors, the rest goes scalar -- bit for bit against the oracle's per-pair routine; and the marginalisation
+    for (int it = 0; it < 60; ++it) {
+        const uint32_t n_reads = 1 + rng() % 12, n_haps = 1 + rng() % 5;
+        const bool same_len = it % 2 == 0;
+        const uint32_t R0 = 1 + rng() % 120, H0 = 1 + rng() % 200;
+        std::vector<uint8_t> rb, rq, ri, rd, rc, hb;
+        std::vector<uint32_t> roff, rlen, hoff, hlen;
+        for (uint32_t r = 0; r < n_reads; ++r) {
+            const uint32_t R = same_len ? R0 : 1 + rng() % 120;
+            roff.push_back((uint32_t)rb.size());
+            rlen.push_back(R);
+            for (uint32_t i = 0; i < R; ++i) {
+                rb.push_back((uint8_t)acgt[rng() % 5]);
+                rq.push_back((uint8_t)(rng() % 200));  // the kernels mask with 127
+                ri.push_back((uint8_t)(10 + rng() % 40));
+                rd.push_back((uint8_t)(10 + rng() % 40));
+                rc.push_back((uint8_t)(5 + rng() % 20));
+            }
+        }
+        for (uint32_t h = 0; h < n_haps; ++h) {
+            const uint32_t H = same_len ? H0 : 1 + rng() % 200;
+            hoff.push_back((uint32_t)hb.size());
+            hlen.push_back(H);
+            for (uint32_t j = 0; j < H; ++j) hb.push_back((uint8_t)acgt[rng() % 5]);
+        }
+        phmm_batch b{};
+        b.n_reads = n_reads;
+        b.n_haps = n_haps;
+        b.read_bases = rb.data();
+        b.read_qual = rq.data();
+        b.read_ins = ri.data();
+        b.read_del = rd.data();
+        b.read_gcp = rc.data();
+        b.read_off = roff.data();
+        b.read_len = rlen.data();
+        b.hap_bases = hb.data();
+        b.hap_off = hoff.data();
+        b.hap_len = hlen.data();  // pair arrays null: the full cross product
+        const size_t n = (size_t)n_reads * n_haps;
+        for (int simd = 0; simd < 2; ++simd) {
+            std::vector<float> raw(n);
+            std::vector<double> raw64(n);
+            std::vector<uint8_t> resc(n);
+            uint64_t n_resc = 0, cells = 0;
+            if (phmm::cpu::compute(b, 1 + rng() % 3, simd != 0, raw.data(), raw64.data(), resc.data(), &n_resc, &cells) != 0) return 4;
+            for (size_t p = 0; p < n; ++p) {
+                const uint32_t r = (uint32_t)(p / n_haps), h = (uint32_t)(p % n_haps);
+                const float want = phmm_oracle_pair_f32(rb.data() + roff[r], rq.data() + roff[r], ri.data() + roff[r], rd.data() + roff[r],
+                                                        rc.data() + roff[r], rlen[r], hb.data() + hoff[h], hlen[h]);
+                if (memcmp(&want, &raw[p], 4) != 0) {
+                    fprintf(stderr, "CPU backend differs from the oracle: pair %zu (simd %d, iteration %d)\n", p, simd, it);
+                    return 5;
+                }
+            }
+            checksum += n_resc + cells;
+        }
+        const uint32_t n_new = 1 + rng() % 4, stride = n_reads + rng() % 3;
+        std::vector<double> old((size_t)n_haps * stride), a((size_t)n_new * n_reads), o((size_t)n_new * n_reads);
+        std::vector<int32_t> map(n_haps);
+        for (auto &v : old) v = (rng() % 11 == 0) ? NAN : -(double)(rng() % 1000) / 7.0;
+        for (auto &m : map) m = (int32_t)(rng() % (n_new + 1)) - 1;
+        rovaca_amd::marginal_likelihoods_direct(old.data(), n_haps, stride, n_reads, map.data(), n_new, a.data());
+        phmm_oracle_marginalize(old.data(), n_haps, stride, n_reads, map.data(), n_new, o.data());
+        if (memcmp(a.data(), o.data(), a.size() * sizeof(double)) != 0) return 6;
     }
     printf("sanitizer run clean, checksum %llu\n", (unsigned long long)checksum);
     return 0;

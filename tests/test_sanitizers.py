@@ -1,4 +1,4 @@
-"""AddressSanitizer + UndefinedBehaviorSanitizer over the CPU-side code: the product's host logic and both oracles
+"""AddressSanitizer + UndefinedBehaviorSanitizer over the CPU-side code: the product's host logic, the CPU backend of the C ABI and both oracles
 (the reference offers the same switch for its own targets, cmake/asan.cmake).  GPU sanitizers are not available on the pool."""
 import os
 import shutil
@@ -23,7 +23,9 @@ def test_host_logic_and_oracles_are_clean_under_asan_ubsan():
             subprocess.run(["gcc", "-std=gnu11"] + flags + ["-c", s, "-o", o], check=True)
             objs.append(o)
         subprocess.run(["g++", "-std=c++17"] + flags + [os.path.join(ROOT, "tests", "sanitize", "host_asan.cpp"),
-                                                         os.path.join(ROOT, "rovaca_amd", "host", "pairhmm_host_logic.cpp")] + objs +
+                                                         os.path.join(ROOT, "rovaca_amd", "host", "pairhmm_host_logic.cpp"),
+                                                         os.path.join(ROOT, "rovaca_amd", "csrc", "pairhmm_cpu.cpp"),
+                                                         os.path.join(ROOT, "rovaca_amd", "csrc", "pairhmm_tables.cpp")] + objs +
                        ["-o", exe, "-lm", "-lpthread"], check=True)
         r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
         assert r.returncode == 0, r.stdout + r.stderr

@@ -58,3 +58,25 @@ def test_two_rank_gloo_matches_single_rank():
     assert np.array_equal(ret["raw"].view(np.uint32), raw.view(np.uint32))
     assert np.array_equal(ret["l10"], l10)
     assert ret["cells"] == b.cells()
+
+
+def test_c_abi_cut_is_the_python_cut():
+    # phmm_create_multi's slices (rovaca_amd/csrc/pairhmm_capi.cpp: partition_equal_cells) against shard.partition_equal_cells:
+    # the same order (rows per lane, haplotype length, pair index) and the same cuts, for explicit pair lists and cross products
+    from rovaca_amd import capi
+    b = synth.make_batch(seed=9, n_regions=12, reads=20, haps=6, read_len=(50, 250), hap_len=(100, 500))
+    rng = np.random.default_rng(3)
+    shuffled = b.subset(rng.permutation(b.n_pairs))
+    for batch in (b, shuffled):
+        for world in (1, 2, 3, 8):
+            which, cells = capi.plan_slices(batch, world)
+            parts = shard.partition_equal_cells(batch, world)
+            want = np.zeros(batch.n_pairs, np.uint32)
+            for g, idx in enumerate(parts):
+                want[idx] = g
+            assert np.array_equal(which, want)
+            assert [int(c) for c in cells] == [batch.subset(p).cells() for p in parts]
+    one = synth.make_batch(seed=10, n_regions=1, reads=30, haps=7, read_len=(40, 200), hap_len=(100, 300))
+    which, cells = capi.plan_slices(one, 4, cross=True)  # the region's pair list IS the cross product in (read, hap) order
+    which2, cells2 = capi.plan_slices(one, 4)
+    assert np.array_equal(which, which2) and np.array_equal(cells, cells2) and int(cells.sum()) == one.cells()
