@@ -228,7 +228,7 @@ struct phmm_resident
     ~phmm_resident() { delete cpu; }
     uint64_t n_pairs = 0, cells = 0;
     uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
-    bool uniform_gcp = false;
+    bool uniform_gcp = false, uniform_gop = false;
     // inputs travel as ONE pinned staging buffer and ONE host-to-device copy per upload (a region-sized submission is
     // latency-bound: fifteen small copies cost more than the sweep); the views below point into `blob`
     HostBuf stage, out_stage;
@@ -486,8 +486,12 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, 
     // (read_record.cpp:205-210, pairhmm_internal.cpp:425) -- selects the kernel variant that shares those constants
     bool ug = read_bytes > 0;
     uint8_t gcp0 = 0;
+    bool ugo = false;  // one gap-open quality for every base as well (PCR-free data, the synthetic configs)
+    if (prep) ugo = prep->pcr_model == 0;  // no PCR model: every base keeps prep->gap_open (read_record.cpp:191-196)
     if (!prep && read_bytes) {
         gcp0 = b->read_gcp[b->read_off[0]] & 127;
+        const uint8_t gop0 = b->read_ins[b->read_off[0]] & 127;
+        uint8_t gop_diff = 0;
         const bool same_array = b->read_del == b->read_ins;
         for (uint32_t r = 0; r < b->n_reads && ug; ++r) {
             const uint8_t *g = b->read_gcp + b->read_off[r];
@@ -498,10 +502,13 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, 
                 for (uint32_t i = 0; i < n; ++i) diff |= (uint8_t)(g[i] ^ gcp0);
             else
                 for (uint32_t i = 0; i < n; ++i) diff |= (uint8_t)((g[i] ^ gcp0) | (gi[i] ^ gd[i]));
+            for (uint32_t i = 0; i < n; ++i) gop_diff |= (uint8_t)(gi[i] ^ gop0);
             ug = (diff & 127) == 0;
         }
+        ugo = ug && (gop_diff & 127) == 0;
     }
     rb->uniform_gcp = ug;
+    rb->uniform_gop = ug && ugo && !getenv("PHMM_NO_UNIFORM_GOP");  // (the variable: tests compare the two kernels)
     // In the Rovaca case two of the five read arrays carry no information: the deletion gap-opens are the insertion ones and
     // the gap-continuation array is one value.  They are not packed or copied: on the device `del` aliases `ins` and `gcp` is
     // a fill (a big one-shot batch spends more host time packing tables than binning pairs).
@@ -1035,13 +1042,13 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
                 if (l == 16 || l == 64) lanes = l;
             }
             const int k = lanes == 64 ? (int)((bin.max_read_len + 63) / 64) : bin.rows_per_lane;
-            HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream));
+            HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream, rb->uniform_gop));
         }
         else if (bin.max_read_len <= 64u * phmm::kMaxRowsPerLaneWide && bin.max_hap_len <= kSinglePassMaxHap &&
                  !getenv("PHMM_NO_WIDE_SINGLE_PASS")) {
             // reads of 257..512 bases: still one pass, a whole wave per pair (no stripes, no carry): measured 20 % faster than
             // the team kernel on 400 x 600
-            HIP_TRY(phmm::launch_systolic_f32((int)((bin.max_read_len + 63) / 64), 64, rb->uniform_gcp, a, stream));
+            HIP_TRY(phmm::launch_systolic_f32((int)((bin.max_read_len + 63) / 64), 64, rb->uniform_gcp, a, stream, rb->uniform_gop));
         }
         else {
             const StripedPlan &pl = plans[i];

@@ -55,7 +55,9 @@ struct KernelArgs
 };
 
 // lanes_per_pair 16: rows_per_lane = ceil(R / 16) in 1..kMaxRowsPerLane; 64: ceil(R / 64) in 1..kMaxRowsPerLaneWide
-hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool uniform_gcp, const KernelArgs &a, hipStream_t s);
+// uniform_gop (only with uniform_gcp): every base of the batch has the same gap-open quality too -> the variant that shares p_mm / p_mx
+hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool uniform_gcp, const KernelArgs &a, hipStream_t s,
+                               bool uniform_gop = false);
 // striped ("team") kernels: a workgroup of waves_per_team waves (1, 4 or 8) sweeps four pairs; lds_words_per_group is
 // kPlanes * planes_words(longest haplotype of the launch); carry holds 3 * carry_stride values per (team, wave, group).
 // lanes_per_pair: 16 (four pairs per wave) or 64 (one pair per wave)

@@ -371,6 +371,209 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
 }
 
 // ----------------------------------------------------------------------------------------------------
+// the systolic kernel for batches with ONE gap-open quality (PCR-free data: --pcr-indel-model NONE leaves every base at 45,
+// read_record.cpp:191-196; BASELINE's synthetic batches use 40 throughout) on top of the Rovaca case above.  Then p_mm and p_mx are
+// the same for every row, and M[i][j] * p_my_i (needed by Y[i][j+1]) is the very number M[i][j] * p_mx_{i+1} (needed by X[i+1][j]):
+// pass 2 computes it, the next step's pass 1 uses it again.  K - 1 multiplications fewer per step (101 VALU instructions instead of
+// 110 at K = 10), 2K - (K - 1) - 2 vector registers fewer, the same bits -- every product is the same operation on the same operands,
+// rounded once.  A copy of the kernel above rather than another template switch in it: that kernel's register allocation is tuned
+// and sensitive to any change of its text ("Register numbers matter").
+// ----------------------------------------------------------------------------------------------------
+template <typename T, int K, int G>
+__global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHMM_MIN_WAVES(T, K, true))
+    pairhmm_systolic_ugo_kernel(KernelArgs a)
+{
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (uint32_t)(G - 1);                      // lane inside the pair's G-lane array
+    const uint32_t grp_in_block = threadIdx.x / (uint32_t)G;                    // 0..15 (G = 16), 0 (G = 64)
+    const uint32_t gidx = blockIdx.x * (systolic_block_threads<G>() / G) + grp_in_block;
+    const bool valid = gidx < a.n_pairs;
+    const uint32_t pair = a.order[valid ? gidx : 0];
+    const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
+    const uint32_t R = a.read_len[r], H = a.hap_len[h];
+    const uint32_t roff = a.read_off[r];
+    const uint32_t W = planes_words(H);
+    const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
+    const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
+
+    // ---- stage this pair's haplotype planes into LDS (kPlanes * W words, 16 lanes copy) ----
+    uint32_t *pl = lds + grp_in_block * a.lds_words_per_group;
+    {
+        const uint32_t *src = a.planes + a.plane_off[h];
+        for (uint32_t i = lane; i < kPlanes * W; i += G) pl[i] = src[i];
+    }
+
+    // ---- constants.  One gap-open and one gap-continuation quality for the whole batch (the host checked): the transition
+    // probabilities are four wave-uniform scalars; per row only what depends on the base quality and on padding remains ----
+    T p_yy[K], lo[K], hi[K];
+    T M[K], X[K], Y[K];
+    T PM[K > 1 ? K - 1 : 1];  // M[k] * p_mx of the anti-diagonal before: computed once in pass 2 (for X of the row below), used again
+                              // in the next step's pass 1 (for Y of the same row) -- the two products are the same number here
+    uint32_t cls_lo = 0, cls_hi = 0;  // 3-bit plane class per row, packed (K <= 16 -> 48 bits)
+    const T init_y = Num<T>::init_const() / static_cast<T>(H);  // rovaca/avx_512_float.cc:32
+    const int pad = G * K - static_cast<int>(R);                  // rows [0, pad) are boundary replicas
+    // kept per lane on purpose: with the four shared factors in SGPRs the sweep ran 6 % slower (a VALU instruction with an SGPR
+    // source issues more slowly on this chip than one whose sources are all VGPRs; measured on config 2, 8.25 ms against 7.76 ms)
+    const uint32_t g0 = a.read_ins[roff] & 127u, c0 = a.read_gcp[roff] & 127u;
+    const T p_mm = mmtab[((g0 * (g0 + 1)) >> 1) + g0];  // core/context.h:162-173 with ins == del
+    const T p_mx = ph2pr[g0];                            // == p_my
+    const T p_gapm = static_cast<T>(1.0) - ph2pr[c0];
+    const T p_xx = ph2pr[c0];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int row = static_cast<int>(lane) * K + k - pad;
+        uint32_t cls = 5;
+        if (row >= 0) {
+            const uint32_t at = roff + static_cast<uint32_t>(row);
+            const uint32_t _q = a.read_qual[at] & 127u;
+            p_yy[k] = p_xx;
+            const T dist = ph2pr[_q];
+            hi[k] = static_cast<T>(1.0) - dist;
+            lo[k] = Num<T>::div3(dist);
+            cls = read_class(a.read_bases[at]);
+            M[k] = 0;
+            X[k] = 0;
+            Y[k] = 0;
+        }
+        else {
+            // boundary replica: prior 0 kills M whatever p_mm is, X stays 0 because everything above it is 0, p_yy = 1 holds Y
+            p_yy[k] = 1;
+            hi[k] = 0;
+            lo[k] = 0;
+            M[k] = 0;
+            X[k] = 0;
+            Y[k] = init_y;
+        }
+        if (k < 10)
+            cls_lo |= cls << (3 * k);
+        else
+            cls_hi |= cls << (3 * (k - 10));
+    }
+#pragma unroll
+    for (int k = 0; k + 1 < K; ++k) PM[k] = 0;
+    __syncthreads();  // planes visible (each group only reads its own, but keep the block-wide fence simple)
+
+    // ---- the sweep ----
+    const uint32_t Tg = valid ? H + (G - 1) : 0;  // last step of this group
+    uint32_t Tmax = Tg;                           // wave-uniform loop bound
+    if (G == 16) {
+        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+    }
+    Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
+
+    uint32_t Tmin = Tg;  // until here every lane of the wave is busy once the pipeline is full
+    if (G == 16) {
+        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
+    }
+    Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
+
+    uint32_t mask[K];
+    // The row above slot 0 travels between lanes in two register sets that swap roles every step: one holds that
+    // row at the current column (written by the DPP shift of this step), the other at the previous column (written
+    // one step earlier).  Lane 0 never receives anything, so its copies keep the boundary row (0, 0, init) for ever;
+    // the DPP's `old` operand is the destination itself, which costs no instruction.  Before a lane's first step
+    // both sets hold column 0 of the row above: Y[0][0] = init when that row is the boundary row or a replica of it
+    // (lane * K <= pad), and 0 when it is a read row (M[i][0] = X[i][0] = Y[i][0] = 0).
+    const T y_col0 = (static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
+    T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
+    T sumM = 0, sumX = 0;
+    const uint32_t wmax = W - 2;
+
+    auto reload = [&](uint32_t t) {
+        // every row's 32-column window of its match plane, starting at this lane's next column
+        const uint32_t jn = t > lane ? t - lane : 1u;  // 1-based
+        uint32_t w = (jn - 1) >> 5;
+        const uint32_t s = (jn - 1) & 31u;
+        w = w < wmax ? w : wmax;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
+            const uint32_t *p = pl + cls * W + w;
+            const uint32_t w0 = p[0], w1 = p[1];
+            mask[k] = (w0 << s) | ((w1 >> 1) >> (31u - s));  // bits [s, s+32) of w0:w1, MSB first (s = 0..31)
+        }
+    };
+
+    // one anti-diagonal.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it at this column.
+    auto step = [&](T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
+        uM0 = dpp_shr1<G>(uM0, M[K - 1]);
+        uX0 = dpp_shr1<G>(uX0, X[K - 1]);
+        uY0 = dpp_shr1<G>(uY0, Y[K - 1]);
+        // Pass 1, bottom row first (in place, as in the general kernel); the M * p_my term of Y comes from the product pass 2 made
+        // of the same M one step ago -- except for the last row, whose M goes to the next lane
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            uint32_t nm;
+            const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
+            mask[k] = nm;
+            const T prior = hit ? hi[k] : lo[k];
+            Y[k] = Num<T>::fma_(Y[k], p_yy[k], k == K - 1 ? M[K - 1] * p_mx : PM[k < K - 1 ? k : 0]);
+            const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
+            T tt = gM * p_mm;
+            tt = Num<T>::fma_(gX, p_gapm, tt);
+            tt = Num<T>::fma_(gY, p_gapm, tt);
+            M[k] = tt * prior;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // Pass 2, top row first: the insertion state chains down the column through the NEW M and X
+        T uM = uM0, uX = uX0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const T prod = uM * p_mx;  // k >= 1: the product of the new M[k - 1], kept for Y[k - 1] of the next step
+            X[k] = Num<T>::fma_(uX, p_xx, prod);
+            if (k >= 1) PM[k - 1] = prod;
+            uM = M[k];
+            uX = X[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
+        sumX = sumX + X[K - 1];
+    };
+    auto step_t = [&](uint32_t t) {
+        if (t & 1u)
+            step(aM, aX, aY, bM, bX, bY);
+        else
+            step(bM, bX, bY, aM, aX, aY);
+    };
+
+    uint32_t t = 1;
+    // fill: lane l starts at step l + 1
+    const uint32_t Tfill = Tmax < (uint32_t)(G - 1) ? Tmax : (uint32_t)(G - 1);
+    for (; t <= Tfill; ++t) {
+        if ((t & 31u) == 1u) reload(t);
+        if ((t > lane) && (t <= Tg)) step_t(t);
+    }
+    // steady state: every lane of all four pairs has work, no per-lane predicate
+    if (t <= Tmin && !(t & 1u)) {
+        step(bM, bX, bY, aM, aX, aY);
+        ++t;
+    }
+    for (; t + 1 <= Tmin; t += 2) {  // t is odd here: the two register sets swap roles without a single move
+        if ((t & 31u) == 1u) reload(t);
+        step(aM, aX, aY, bM, bX, bY);
+        step(bM, bX, bY, aM, aX, aY);
+    }
+    if (t <= Tmin) {
+        if ((t & 31u) == 1u) reload(t);
+        step(aM, aX, aY, bM, bX, bY);
+        ++t;
+    }
+    // drain: pairs with a shorter haplotype than the longest of the wave drop out group by group
+    for (; t <= Tmax; ++t) {
+        if ((t & 31u) == 1u) reload(t);
+        if (t <= Tg) step_t(t);
+    }
+    if (valid && lane == G - 1) {
+        const T res = sumM + sumX;
+        reinterpret_cast<T *>(a.out_raw)[pair] = res;
+        if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))  // pairhmm_internal.cpp:578: queue for fp64
+            a.rescue_list[atomicAdd(a.rescue_count, 1u)] = pair;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
 // the striped ("team") systolic kernel: reads longer than 16 * K rows, very long haplotypes, and every fp64 re-run.
 //
 // The read is cut into stripes of S = 16 * K rows, right-aligned (the boundary replicas sit on top of stripe 0, the last
@@ -1372,6 +1575,27 @@ static hipError_t launch_one(const KernelArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+template <typename T, int K, int G>
+static hipError_t launch_one_ugo(const KernelArgs &a, hipStream_t s)
+{
+    constexpr uint32_t threads = systolic_block_threads<G>();
+    const uint32_t groups_per_block = threads / G;
+    const uint32_t blocks = (a.n_pairs + groups_per_block - 1) / groups_per_block;
+    const size_t shmem = static_cast<size_t>(groups_per_block) * a.lds_words_per_group * sizeof(uint32_t);
+    hipLaunchKernelGGL((pairhmm_systolic_ugo_kernel<T, K, G>), dim3(blocks), dim3(threads), shmem, s, a);
+    return hipGetLastError();
+}
+
+template <typename T, int G, int K>
+static hipError_t launch_k_ugo(int k, const KernelArgs &a, hipStream_t s)
+{
+    if (k == K) return launch_one_ugo<T, K, G>(a, s);
+    if constexpr (K < (G == 64 ? kMaxRowsPerLaneWide : kMaxRowsPerLane))
+        return launch_k_ugo<T, G, K + 1>(k, a, s);
+    else
+        return hipErrorInvalidValue;
+}
+
 template <typename T, bool UG, int G, int K>
 static hipError_t launch_k(int k, const KernelArgs &a, hipStream_t s)
 {
@@ -1382,9 +1606,14 @@ static hipError_t launch_k(int k, const KernelArgs &a, hipStream_t s)
         return hipErrorInvalidValue;
 }
 
-hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool uniform_gcp, const KernelArgs &a, hipStream_t s)
+hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool uniform_gcp, const KernelArgs &a, hipStream_t s, bool uniform_gop)
 {
     if (a.n_pairs == 0) return hipSuccess;
+    if (uniform_gcp && uniform_gop) {
+        if (lanes_per_pair == 64) return launch_k_ugo<float, 64, 1>(rows_per_lane, a, s);
+        if (lanes_per_pair == 16) return launch_k_ugo<float, 16, 1>(rows_per_lane, a, s);
+        return hipErrorInvalidValue;
+    }
     if (lanes_per_pair == 64)
         return uniform_gcp ? launch_k<float, true, 64, 1>(rows_per_lane, a, s) : launch_k<float, false, 64, 1>(rows_per_lane, a, s);
     if (lanes_per_pair != 16) return hipErrorInvalidValue;

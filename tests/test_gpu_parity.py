@@ -385,3 +385,42 @@ def test_band_kernel_pair_joining_late_beside_a_stripe_that_began_mid_row(engine
         reads.append((seq, q, g, g, np.full(R, 10, np.uint8)))
     pairs = [(r, h) for r in range(len(reads)) for h in range(len(haps))]
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
+
+
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_uniform_gap_open_kernel_is_the_general_one(engine, lanes, monkeypatch):
+    # batches with one gap-open quality throughout (PCR-free data, the synthetic configs) take the variant that shares p_mm / p_mx
+    # and reuses M * p_mx for the Y of the next step: same bits as the Rovaca-case kernel (PHMM_NO_UNIFORM_GOP=1) and as the oracle,
+    # for every rows-per-lane value, with padding rows, N and foreign symbols; a batch with ONE deviating base must not take it
+    monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGTN", np.uint8)
+    reads, haps, pairs = [], [], []
+    for R in list(range(1, 36)) + [47, 48, 49, 63, 64, 65, 100, 127, 128, 129, 150, 151, 160, 161, 175, 176, 177, 200, 239, 240, 241, 255, 256]:
+        H = int(rng.integers(max(R, 20), R + 300))
+        hap = acgt[rng.integers(0, 5 if R % 7 == 0 else 4, H)]
+        a0 = int(rng.integers(0, H - R + 1))
+        seq = hap[a0:a0 + R].copy()
+        seq[rng.random(R) < 0.03] = acgt[rng.integers(0, 5)]
+        q = rng.choice(np.array([6, 18, 25, 37, 41], np.uint8), R)
+        g = np.full(R, 45, np.uint8)
+        reads.append((seq, q, g, g.copy(), np.full(R, 10, np.uint8)))
+        haps.append(hap)
+        pairs.append((len(reads) - 1, len(haps) - 1))
+    pairs += [(i, (i * 7 + 3) % len(haps)) for i in range(len(reads))]
+    b = Batch.from_lists(reads, haps, pairs)
+    raw, l10 = _check_against_oracle(engine, b)
+    monkeypatch.setenv("PHMM_NO_UNIFORM_GOP", "1")
+    raw2, l10_2, _ = engine.compute(b)
+    monkeypatch.delenv("PHMM_NO_UNIFORM_GOP")
+    assert np.array_equal(raw.view(np.uint32), raw2.view(np.uint32)) and np.array_equal(l10, l10_2, equal_nan=True)
+    b.read_ins[len(b.read_ins) // 2] = 39  # one base with another gap-open (del aliases ins here: both arrays must change)
+    b.read_del[len(b.read_del) // 2] = 39
+    _check_against_oracle(engine, b)
+    # device-side read preparation without a PCR model leaves one gap-open too
+    mapq = np.full(b.n_reads, 60, np.uint8)
+    praw, _, _ = engine.compute(b, prep=(mapq, 0, 0))
+    b.read_ins[:] = 45
+    b.read_del[:] = 45
+    hraw, _, _ = engine.compute(b)
+    assert np.array_equal(praw.view(np.uint32), hraw.view(np.uint32))

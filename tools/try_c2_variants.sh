@@ -1,6 +1,6 @@
 #!/bin/bash
 # tuning aid: headline configuration against alternative builds of the HIP library (rovaca_amd/lib/variants/lib_*.so)
-run() { timeout -k 5 150 python bench.py --no-cpu-baseline 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; }
+run() { timeout -k 5 150 python bench.py --no-cpu-baseline --no-e2e 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; }
 echo "=== baseline"; run
 for v in rovaca_amd/lib/variants/lib_*.so; do
   echo "=== $v"
