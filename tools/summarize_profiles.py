@@ -20,7 +20,7 @@ for c in ("c2", "c3", "c5"):
         shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, c)))
         stats[c] = list(csv.DictReader(open(f)))
 
-hot = next(r for r in stats["c2"] if "pairhmm_systolic_kernel" in r["Name"])
+hot = next(r for r in stats["c2"] if "pairhmm_systolic" in r["Name"])  # rows are sorted by total time
 bench_ms = None
 m = re.search(r'"kernel_ms": ([0-9.]+)', open(os.path.join(src, "bench_c2.log")).read())
 if m:
@@ -29,7 +29,7 @@ if m:
 counters = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "pairhmm_systolic_kernel" not in r["Kernel_Name"]:
+        if "pairhmm_systolic" not in r["Kernel_Name"]:
             continue
         counters.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
         counters[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
