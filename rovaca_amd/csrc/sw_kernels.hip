@@ -129,41 +129,43 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
             for (uint32_t w = 0; w < W; ++w) words[w] = 0;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                // One cell = 19 full-rate VALU instructions, written out by hand.  On gfx950 v_max_i32, v_alignbit_b32 and
-                // every compare/select that goes through an SGPR pair issue at HALF the rate of v_add_u32 / VOPC-to-VCC /
-                // v_cndmask-from-VCC / v_addc_co (tools/ubench_valu.hip), and hipcc picks exactly those.  So each maximum is
-                // a compare into VCC, a select out of VCC, and v_addc_co_u32 acc, vcc, acc, acc, vcc appends the same bit to
-                // the flag word.  Scores live biased by 2^30 (unsigned compares are then signed compares).  Two wait states
-                // are needed between a VALU write of VCC and a VALU read of it; independent work fills them where there is
-                // some, s_nop where there is none (inline assembly is not visible to the hazard recogniser).
+                // One cell = 19 VALU instructions, written out by hand around what tools/ubench_valu.hip measures on gfx950 (cycles per
+                // wave instruction and SIMD at 4 waves): v_add_u32, v_sub_co_u32, v_cndmask-from-VCC and the VOP2 logic ops issue at
+                // full rate (2.4-2.7); v_cmp to VCC, v_addc_co_u32 (carry in AND out), v_max/v_min, v_alignbit, v_lshl_add, v_and_or
+                // and every compare/select through an SGPR pair at HALF rate (4.2-4.4) -- and hipcc picks those.  So each maximum is
+                // v_sub_co_u32 (its borrow is "a < b"; the difference is thrown away), a select out of VCC, and v_addc_co_u32 acc, vcc,
+                // acc, acc, vcc appends the same bit to the flag word (half rate, but so is every other one-instruction way to append a
+                // bit).  Only the base comparison stays a VOPC.  Scores live biased by 2^30 (unsigned order is then signed order).  Two
+                // wait states between a VALU write of VCC and a VALU read of it; independent work fills them where there is some,
+                // s_nop where there is none (inline assembly is not visible to the hazard recogniser).
                 uint32_t e11, f11 = F[k], h11, acc = words[k / 8];  // f11: F[i-1][j] in, F[i][j] out
-                uint32_t t_exth, t_openh, t_sc, t_m11, t_extv, t_openv, t_h1;
+                uint32_t t_exth, t_openh, t_sc, t_m11, t_extv, t_openv, t_h1, t_d;
                 asm volatile(
                     "v_cmp_eq_u32 vcc, %[b1], %[b2]\n\t"
                     "v_add_u32 %[exth], %[e], %[wext]\n\t"
                     "v_add_u32 %[openh], %[hl], %[wopen]\n\t"
                     "v_cndmask_b32 %[sc], %[wmm], %[wm], vcc\n\t"
-                    "v_cmp_lt_u32 vcc, %[exth], %[openh]\n\t"      // E: the gap opens here (extension wins ties)
+                    "v_sub_co_u32 %[d], vcc, %[exth], %[openh]\n\t"   // E: the gap opens here (extension wins ties)
                     "v_add_u32 %[m11], %[hd], %[sc]\n\t"
                     "v_add_u32 %[extv], %[f11], %[wext]\n\t"
                     "v_cndmask_b32 %[e11], %[exth], %[openh], vcc\n\t"
                     "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
                     "v_add_u32 %[openv], %[hp], %[wopen]\n\t"
-                    "v_cmp_lt_u32 vcc, %[extv], %[openv]\n\t"      // F: the gap opens here
+                    "v_sub_co_u32 %[d], vcc, %[extv], %[openv]\n\t"   // F: the gap opens here
                     "s_nop 1\n\t"
                     "v_cndmask_b32 %[f11], %[extv], %[openv], vcc\n\t"
                     "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
-                    "v_cmp_lt_u32 vcc, %[m11], %[e11]\n\t"          // E beats the diagonal: insertion
+                    "v_sub_co_u32 %[d], vcc, %[m11], %[e11]\n\t"       // E beats the diagonal: insertion
                     "s_nop 1\n\t"
                     "v_cndmask_b32 %[h1], %[m11], %[e11], vcc\n\t"
                     "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
-                    "v_cmp_lt_u32 vcc, %[h1], %[f11]\n\t"           // F beats both: deletion
+                    "v_sub_co_u32 %[d], vcc, %[h1], %[f11]\n\t"        // F beats both: deletion
                     "s_nop 1\n\t"
                     "v_cndmask_b32 %[h11], %[h1], %[f11], vcc\n\t"
                     "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
                     : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "+v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth),
                       [openh] "=&v"(t_openh), [sc] "=&v"(t_sc), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv),
-                      [h1] "=&v"(t_h1)
+                      [h1] "=&v"(t_h1), [d] "=&v"(t_d)
                     : [b1] "v"(base1), [b2] "v"(base2[k]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [hp] "v"(Hp[k]),
                       [wext] "v"(vw_extend), [wopen] "v"(vw_open), [wm] "v"(vw_match), [wmm] "v"(vw_mismatch)
                     : "vcc");
@@ -261,8 +263,14 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
         }
     }
 
-    // ---- traceback and CIGAR (sw_avx.c:256-362), one lane per alignment ----
-    if (valid && lane == 0) {
+    // ---- traceback and CIGAR (sw_avx.c:256-362) ----
+    // The walk is a chain of dependent loads of backtrack words that mostly sit in HBM by now (a launch writes gigabytes of them),
+    // and nearly every move is diagonal.  So the G lanes of the alignment walk together: lane q fetches the flags of cell
+    // (i - q, j - q) -- the next G cells if the path stays on this diagonal -- and then every lane runs the same state machine over
+    // them (values passed with a shuffle; i, j and the state are uniform over the group), stopping at the first move that leaves the
+    // diagonal, where the fetch is repeated from the new cell.  One round trip to memory per G diagonal moves instead of one per move.
+    // Only lane 0 writes.
+    if (valid) {
         int32_t i = max_i, j = max_j;
         uint32_t n_el = 0;
         int32_t cur_state = -1, cur_len = 0;  // the element being built; equal neighbours are merged as they come
@@ -271,16 +279,17 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 cur_len += len;
             }
             else {
-                if (cur_state >= 0) elems[n_el++] = ((uint32_t)cur_len << 4) | (uint32_t)cur_state;
+                if (cur_state >= 0) {
+                    if (lane == 0) elems[n_el] = ((uint32_t)cur_len << 4) | (uint32_t)cur_state;
+                    ++n_el;
+                }
                 cur_state = state;
                 cur_len = len;
             }
         };
-        if (j < ncol) emit((int32_t)kOpS, ncol - j);
-        uint32_t state = 0;
-        while (i > 0 && j > 0) {
-            const uint32_t l = (uint32_t)(j - 1) / K, k = (uint32_t)(j - 1) % K;
-            const uint32_t t = (uint32_t)i + l;
+        auto flags_of = [&](int32_t ci, int32_t cj) -> uint32_t {
+            const uint32_t l = (uint32_t)(cj - 1) / K, k = (uint32_t)(cj - 1) % K;
+            const uint32_t t = (uint32_t)ci + l;
             const size_t slot = (size_t)(t - 1) * G + l;
             uint32_t word;
             if (k / 8 < W32)
@@ -293,41 +302,54 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 word = reinterpret_cast<const uint32_t *>(bt_tail)[slot];
             constexpr uint32_t last_cells = K % 8 == 0 ? 8u : (uint32_t)(K % 8);      // cells in the last (partial) word
             const uint32_t in_word = k / 8 + 1 == W ? last_cells : 8u;
-            const uint32_t nib = (word >> (4 * (in_word - 1 - k % 8))) & 15u;          // first cell of a word sits highest
-            // back to the reference's flags (smithwaterman_common.h:41-46)
-            const uint32_t btr = ((nib & 8u) ? 0u : (uint32_t)kBtInsertExt) | ((nib & 4u) ? 0u : (uint32_t)kBtDeleteExt) |
-                                 ((nib & 1u) ? (uint32_t)kBtDelete : (nib & 2u) ? (uint32_t)kBtInsert : 0u);
-            if (state == kBtInsertExt) {
-                --j;
-                cur_len += 1;  // lengthens the insertion that is being built
-                state = btr & kBtInsertExt;
-            }
-            else if (state == kBtDeleteExt) {
-                --i;
-                cur_len += 1;
-                state = btr & kBtDeleteExt;
-            }
-            else {
-                const uint32_t op = btr & 3u;
-                if (op == kBtInsert) {
+            return (word >> (4 * (in_word - 1 - k % 8))) & 15u;                         // first cell of a word sits highest
+        };
+        if (j < ncol) emit((int32_t)kOpS, ncol - j);
+        uint32_t state = 0;
+        while (i > 0 && j > 0) {
+            const int32_t ci = i - (int32_t)lane, cj = j - (int32_t)lane;
+            const uint32_t mine = (ci > 0 && cj > 0) ? flags_of(ci, cj) : 0u;
+            bool on_diagonal = true;
+            for (uint32_t q = 0; q < (uint32_t)G && on_diagonal && i > 0 && j > 0; ++q) {
+                const uint32_t nib = (uint32_t)__shfl((int)mine, (int)q, G);
+                // back to the reference's flags (smithwaterman_common.h:41-46)
+                const uint32_t btr = ((nib & 8u) ? 0u : (uint32_t)kBtInsertExt) | ((nib & 4u) ? 0u : (uint32_t)kBtDeleteExt) |
+                                     ((nib & 1u) ? (uint32_t)kBtDelete : (nib & 2u) ? (uint32_t)kBtInsert : 0u);
+                on_diagonal = false;
+                if (state == kBtInsertExt) {
                     --j;
-                    emit((int32_t)kOpI, 1);
+                    cur_len += 1;  // lengthens the insertion that is being built
                     state = btr & kBtInsertExt;
                 }
-                else if (op == kBtDelete) {
+                else if (state == kBtDeleteExt) {
                     --i;
-                    emit((int32_t)kOpD, 1);
+                    cur_len += 1;
                     state = btr & kBtDeleteExt;
                 }
                 else {
-                    --i;
-                    --j;
-                    emit((int32_t)kOpM, 1);
-                    state = 0;
+                    const uint32_t op = btr & 3u;
+                    if (op == kBtInsert) {
+                        --j;
+                        emit((int32_t)kOpI, 1);
+                        state = btr & kBtInsertExt;
+                    }
+                    else if (op == kBtDelete) {
+                        --i;
+                        emit((int32_t)kOpD, 1);
+                        state = btr & kBtDeleteExt;
+                    }
+                    else {
+                        --i;
+                        --j;
+                        emit((int32_t)kOpM, 1);
+                        state = 0;
+                        on_diagonal = true;
+                    }
                 }
             }
         }
         if (j > 0) emit((int32_t)kOpS, j);
+        if (lane != 0) return;
         if (cur_state >= 0) elems[n_el++] = ((uint32_t)cur_len << 4) | (uint32_t)cur_state;
         // reversed into the output; the reference's element buffer holds kMaxSeqLen - 1 of them (sw_avx.c:349-358)
         const uint32_t count = n_el < (uint32_t)(kMaxSeqLen - 1) ? n_el : (uint32_t)(kMaxSeqLen - 1);

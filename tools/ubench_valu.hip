@@ -32,6 +32,24 @@ __global__ void k(float* out, int iters, unsigned long long* clk)
         if (MODE == 10) { REP8(asm volatile("v_sub_u32 %2, %0, %1\n v_alignbit_b32 %3, %3, %2, 31\n v_sub_u32 %4, %1, %0\n v_alignbit_b32 %3, %3, %4, 31\n v_sub_u32 %2, %0, %1\n v_alignbit_b32 %3, %3, %2, 31\n v_sub_u32 %4, %1, %0\n v_alignbit_b32 %3, %3, %4, 31" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 11) { REP8(asm volatile("v_cmp_eq_u32_e64 s[20:21], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %2, %4, %5, s[20:21]\n v_cmp_gt_i32_e64 s[22:23], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %3, %4, %5, s[22:23]\n v_cmp_eq_u32_e64 s[20:21], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %2, %4, %5, s[20:21]\n v_cmp_gt_i32_e64 s[22:23], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %3, %4, %5, s[22:23]" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "s20", "s21", "s22", "s23");) }
         if (MODE == 12) { REP8(asm volatile("v_alignbit_b32 %0, %0, %1, 31\n v_alignbit_b32 %2, %2, %1, 31\n v_alignbit_b32 %3, %3, %1, 31\n v_alignbit_b32 %4, %4, %1, 31\n v_alignbit_b32 %0, %0, %1, 31\n v_alignbit_b32 %2, %2, %1, 31\n v_alignbit_b32 %3, %3, %1, 31\n v_alignbit_b32 %4, %4, %1, 31" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        // compare -> select -> carry-append chains as in the Smith-Waterman cell: (13) hazard covered by s_nop 1, (14) by two independent adds,
+        // (15) by one add + s_nop 0; 4 VALU per group in 13, 6 in 14, 5 in 15 (per_iter is 64 VALU: 16 / 10.67 / 12.8 groups -- use 48 VALU for 14/15: see run())
+        if (MODE == 13) { REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %2, %0, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_cmp_lt_u32 vcc, %1, %0\n s_nop 1\n v_cndmask_b32 %4, %0, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4) : : "vcc");) }
+        if (MODE == 14) { REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_add_u32 %5, %5, %0\n v_add_u32 %6, %6, %1\n v_cndmask_b32 %2, %0, %1, vcc\n v_cmp_lt_u32 vcc, %1, %0\n v_add_u32 %5, %5, %0\n v_add_u32 %6, %6, %1\n v_cndmask_b32 %4, %0, %1, vcc" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6) : : "vcc");) }
+        if (MODE == 15) { REP8(asm volatile("v_add_u32 %5, %5, %0\n v_add_u32 %6, %6, %1\n v_cmp_lt_u32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %2, %0, %1, vcc\n v_add_u32 %5, %5, %0\n v_add_u32 %6, %6, %1\n v_cmp_lt_u32 vcc, %1, %0\n s_nop 1\n v_cndmask_b32 %4, %0, %1, vcc" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6) : : "vcc");) }
+        if (MODE == 16) { REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %2, %0, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %4, %0, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %0" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4) : : "vcc");) }
+        // the same chains with the compare done by v_sub_co_u32 (borrow = a < b) instead of VOPC
+        if (MODE == 17) { REP8(asm volatile("v_sub_co_u32 %5, vcc, %0, %1\n v_cndmask_b32 %2, %0, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_sub_co_u32 %5, vcc, %1, %0\n v_cndmask_b32 %4, %0, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %0" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : : "vcc");) }
+        if (MODE == 18) { REP8(asm volatile("v_sub_co_u32 %5, vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %2, %0, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_sub_co_u32 %5, vcc, %1, %0\n s_nop 1\n v_cndmask_b32 %4, %0, %1, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %0" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : : "vcc");) }
+        if (MODE == 19) { REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %0\n v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %0\n v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %0\n v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %0" : "+v"(m0), "+v"(m1) : : "vcc");) }
+        if (MODE == 20) { REP8(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %2, %0, %1, vcc\n v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %3, %0, %1, vcc\n v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %4, %0, %1, vcc\n v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %2, %0, %1, vcc" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4) : : "vcc");) }
+        if (MODE == 21) { REP8(asm volatile("v_sub_co_u32 %5, vcc, %0, %1\n v_cndmask_b32 %2, %0, %1, vcc\n v_sub_co_u32 %5, vcc, %1, %0\n v_cndmask_b32 %3, %0, %1, vcc\n v_sub_co_u32 %5, vcc, %0, %1\n v_cndmask_b32 %4, %0, %1, vcc\n v_sub_co_u32 %5, vcc, %1, %0\n v_cndmask_b32 %2, %0, %1, vcc" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : : "vcc");) }
+        if (MODE == 22) { REP8(asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3) : : "vcc");) }
+        if (MODE == 23) { REP8(asm volatile("v_lshl_add_u32 %0, %0, 1, %2\n v_lshl_add_u32 %1, %1, 1, %2\n v_lshl_add_u32 %3, %3, 1, %2\n v_lshl_add_u32 %4, %4, 1, %2\n v_lshl_add_u32 %0, %0, 1, %2\n v_lshl_add_u32 %1, %1, 1, %2\n v_lshl_add_u32 %3, %3, 1, %2\n v_lshl_add_u32 %4, %4, 1, %2" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        if (MODE == 24) { REP8(asm volatile("v_sub_co_u32 %5, vcc, %0, %1\n v_cndmask_b32 %2, %0, %1, vcc\n v_lshrrev_b32 %5, 31, %5\n v_sub_co_u32 %6, vcc, %1, %0\n v_cndmask_b32 %4, %0, %1, vcc\n v_lshrrev_b32 %6, 31, %6\n v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %0" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6) : : "vcc");) }
+        if (MODE == 25) { REP8(asm volatile("v_and_or_b32 %0, %0, %2, %1\n v_and_or_b32 %1, %1, %2, %0\n v_and_or_b32 %3, %3, %2, %1\n v_and_or_b32 %4, %4, %2, %0\n v_and_or_b32 %0, %0, %2, %1\n v_and_or_b32 %1, %1, %2, %0\n v_and_or_b32 %3, %3, %2, %1\n v_and_or_b32 %4, %4, %2, %0" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        if (MODE == 26) { REP8(asm volatile("v_min_u32 %0, %0, %2\n v_min_u32 %1, %1, %2\n v_max_u32 %3, %3, %2\n v_max_u32 %4, %4, %2\n v_min_u32 %0, %0, %2\n v_min_u32 %1, %1, %2\n v_max_u32 %3, %3, %2\n v_max_u32 %4, %4, %2" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        if (MODE == 27) { REP8(asm volatile("v_xor_b32 %0, %0, %2\n v_and_b32 %1, %1, %2\n v_or_b32 %3, %3, %2\n v_lshlrev_b32 %4, 1, %4\n v_xor_b32 %0, %0, %2\n v_and_b32 %1, %1, %2\n v_or_b32 %3, %3, %2\n v_lshrrev_b32 %4, 1, %4" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 7) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -42,7 +60,7 @@ __global__ void k(float* out, int iters, unsigned long long* clk)
 
 template <int MODE> void run(const char* name, float* out, unsigned long long* clk)
 {
-    const int iters = 2000, per_iter = 64;
+    const int iters = 2000, per_iter = MODE == 13 ? 48 : 64;  // VALU instructions per loop iteration (s_nop not counted)
     printf("%-34s", name); fflush(stdout);
     for (int wps : {1, 2, 4, 8}) {
         int threads = 256, blocks = 256 * wps;  // 256 CUs x (wps waves/SIMD x 4 SIMD / 4 waves per block)
@@ -118,6 +136,21 @@ int main()
     run<9>("v_max_i32 (2 chains)", out, clk);
     run<10>("v_sub_u32 + v_alignbit_b32", out, clk);
     run<12>("v_alignbit_b32 (4 indep)", out, clk);
+    run<13>("cmp, s_nop 1, cndmask, addc", out, clk);
+    run<14>("cmp, add, add, cndmask", out, clk);
+    run<15>("add, add, cmp, s_nop 1, cndmask", out, clk);
+    run<16>("cmp, cndmask, addc (NO nop) + adds", out, clk);
+    run<17>("sub_co, cndmask, addc (no nop) + adds", out, clk);
+    run<18>("sub_co, s_nop 1, cndmask, addc + adds", out, clk);
+    run<19>("v_cmp_lt_u32 to vcc (8 indep)", out, clk);
+    run<20>("v_cmp, cndmask back to back", out, clk);
+    run<21>("v_sub_co, cndmask back to back", out, clk);
+    run<22>("v_addc_co_u32 (carry in and out)", out, clk);
+    run<23>("v_lshl_add_u32", out, clk);
+    run<24>("sub_co, cndmask, lshrrev + adds", out, clk);
+    run<25>("v_and_or_b32", out, clk);
+    run<26>("v_min_u32 / v_max_u32", out, clk);
+    run<27>("v_xor/and/or/lshl/lshr (VOP2)", out, clk);
     run<11>("v_cmp_e64 sgpr + s_nop 1 + v_cndmask_e64 (counted as 2)", out, clk);
     run_salu<0>("8 v_fma + 0 SALU", out, clk);
     run_salu<2>("8 v_fma + 4 SALU (interleaved)", out, clk);
