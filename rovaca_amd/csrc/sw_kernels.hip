@@ -207,6 +207,10 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     Tsteady = __builtin_amdgcn_readfirstlane(Tsteady);
     int32_t t = 1;
     for (; t < G && t <= Tmax; ++t) step(t, std::false_type{});
+    for (; t + 1 <= Tsteady; t += 2) {  // two steps per trip: the row above (Hp) alternates between two register sets instead of being copied
+        step(t, std::true_type{});
+        step(t + 1, std::true_type{});
+    }
     for (; t <= Tsteady; ++t) step(t, std::true_type{});
     for (; t <= Tmax; ++t) step(t, std::false_type{});
     __threadfence_block();  // this lane's own stores are visible to the loads below (same work-item or same wave)
