@@ -100,7 +100,7 @@ if os.path.exists(f):
             % (valu / waves, valu / waves / 415, valu / waves / 4150),
             "         including end-cell search and traceback); over %.2f ms at 2.05 GHz the 1 024 SIMDs spend %.2f cycles per VALU"
             % (ms, ms * 1e-3 * 2.05e9 * 1024 / valu),
-            "         instruction; tools/ubench_valu.hip measures 2.7 for v_add_u32 and 2.55 for compare/select/add-with-carry through VCC.",
+            "         instruction; tools/ubench_valu.hip measures 2.4-2.7 for v_add_u32 / v_sub_co_u32 / v_cndmask and 4.2-4.4 for v_cmp to VCC and v_addc_co_u32.",
         ]
     if "WRITE_SIZE" in mean:
         txt += ["bound: integer VALU.  HBM traffic is the backtrack flags (4 bits per cell): %.2f GB written per launch = %.2f TB/s, %.0f %% of 8 TB/s;"
