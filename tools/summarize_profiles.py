@@ -61,7 +61,8 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     json.dump({"c2": int(2 * fetch + write),
                "_note": "bytes per launch of %s on config c2: 2 x FETCH_SIZE (gfx950 correction, upper bound) + WRITE_SIZE, "
                         "from profiles/%s_c2_pmc_summary.txt" % (hot["Name"].replace("void ", "").split("(")[0], tag),
-               "c2_fetch_raw_bytes": int(fetch), "c2_write_bytes": int(write)},
+               "c2_fetch_raw_bytes": int(fetch), "c2_write_bytes": int(write),
+               "c2_valu_wave_instructions": int(mean.get("SQ_INSTS_VALU", 0)), "c2_kernel": hot["Name"].replace("void ", "").split("(")[0]},
               open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
 for c in stats:
