@@ -132,6 +132,43 @@ def test_every_geometry_and_long_sequences(aligner, lanes, lds_flags, monkeypatc
         _check(aligner, refs, seqs, pairs, params)
 
 
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_gap_rich_paths_leave_the_diagonal_often(aligner, lanes, monkeypatch):
+    # the traceback is walked by all lanes of an alignment together, fetching the flags of the next cells along the diagonal
+    # (sw_kernels.hip): paths with many short and long gaps, runs that open and extend in both directions, unrelated sequences
+    # and low-complexity repeats make it re-fetch at every kind of move; parameters with cheap gaps make the gaps frequent
+    monkeypatch.setenv("SWHIP_FORCE_LANES", str(lanes))
+    monkeypatch.setenv("SWHIP_NO_LDS_FLAGS", "1")
+    rng = np.random.default_rng(31 + lanes)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    refs, seqs, pairs = [], [], []
+    for case in range(120):
+        n1 = int(rng.integers(20, 700))
+        ref = acgt[rng.integers(0, 4, n1)] if case % 5 else np.tile(acgt[rng.integers(0, 4, 3)], n1 // 3 + 1)[:n1]
+        kind = case % 4
+        if kind == 0:  # unrelated
+            seq = acgt[rng.integers(0, 4, int(rng.integers(10, 400)))]
+        else:          # a copy with insertions and deletions of 1..12 bases every 8..40 bases
+            out, x = [], 0
+            while x < n1:
+                step = int(rng.integers(8, 40))
+                out.append(ref[x:x + step])
+                x += step
+                g = int(rng.integers(1, 13))
+                if rng.random() < 0.5:
+                    out.append(acgt[rng.integers(0, 4, g)])  # insertion
+                else:
+                    x += g                                   # deletion
+            seq = np.concatenate(out)[:600]
+            if kind == 3 and len(seq) > 30:
+                seq = seq[int(rng.integers(0, 15)):len(seq) - int(rng.integers(0, 15))]
+        refs.append(ref)
+        seqs.append(seq)
+        pairs.append((len(refs) - 1, len(seqs) - 1))
+    for params in (swapi.PARAMS_GENOTYPE, swapi.PARAMS_ASSEMBLE, (3, -2, -3, -1), (1, -1, -1, -1)):
+        _check(aligner, refs, seqs, pairs, params)
+
+
 def test_too_long_and_invalid(aligner):
     rng = np.random.default_rng(10)
     acgt = np.frombuffer(b"ACGT", np.uint8)
