@@ -50,6 +50,10 @@ __global__ void k(float* out, int iters, unsigned long long* clk)
         if (MODE == 25) { REP8(asm volatile("v_and_or_b32 %0, %0, %2, %1\n v_and_or_b32 %1, %1, %2, %0\n v_and_or_b32 %3, %3, %2, %1\n v_and_or_b32 %4, %4, %2, %0\n v_and_or_b32 %0, %0, %2, %1\n v_and_or_b32 %1, %1, %2, %0\n v_and_or_b32 %3, %3, %2, %1\n v_and_or_b32 %4, %4, %2, %0" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 26) { REP8(asm volatile("v_min_u32 %0, %0, %2\n v_min_u32 %1, %1, %2\n v_max_u32 %3, %3, %2\n v_max_u32 %4, %4, %2\n v_min_u32 %0, %0, %2\n v_min_u32 %1, %1, %2\n v_max_u32 %3, %3, %2\n v_max_u32 %4, %4, %2" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 27) { REP8(asm volatile("v_xor_b32 %0, %0, %2\n v_and_b32 %1, %1, %2\n v_or_b32 %3, %3, %2\n v_lshlrev_b32 %4, 1, %4\n v_xor_b32 %0, %0, %2\n v_and_b32 %1, %1, %2\n v_or_b32 %3, %3, %2\n v_lshrrev_b32 %4, 1, %4" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        // packed 16-bit integer ops (two Smith-Waterman cells per instruction if they issue at full rate)
+        if (MODE == 28) { REP8(asm volatile("v_pk_add_u16 %0, %0, %2\n v_pk_add_u16 %1, %1, %2\n v_pk_sub_i16 %3, %3, %2\n v_pk_sub_i16 %4, %4, %2\n v_pk_add_u16 %0, %0, %2\n v_pk_add_u16 %1, %1, %2\n v_pk_sub_i16 %3, %3, %2\n v_pk_sub_i16 %4, %4, %2" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        if (MODE == 29) { REP8(asm volatile("v_pk_max_i16 %0, %0, %2\n v_pk_max_i16 %1, %1, %2\n v_pk_min_i16 %3, %3, %2\n v_pk_min_u16 %4, %4, %2\n v_pk_max_i16 %0, %0, %2\n v_pk_max_i16 %1, %1, %2\n v_pk_min_i16 %3, %3, %2\n v_pk_min_u16 %4, %4, %2" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        if (MODE == 30) { REP8(asm volatile("v_pk_lshrrev_b16 %0, 15, %0\n v_pk_lshlrev_b16 %1, 1, %1\n v_pk_ashrrev_i16 %3, 15, %3\n v_pk_mad_u16 %4, %4, %2, %1\n v_pk_lshrrev_b16 %0, 15, %0\n v_pk_lshlrev_b16 %1, 1, %1\n v_pk_ashrrev_i16 %3, 15, %3\n v_pk_mad_u16 %4, %4, %2, %1" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 7) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -151,6 +155,9 @@ int main()
     run<25>("v_and_or_b32", out, clk);
     run<26>("v_min_u32 / v_max_u32", out, clk);
     run<27>("v_xor/and/or/lshl/lshr (VOP2)", out, clk);
+    run<28>("v_pk_add_u16 / v_pk_sub_i16", out, clk);
+    run<29>("v_pk_max_i16 / v_pk_min_i16 / min_u16", out, clk);
+    run<30>("v_pk_lshr/lshl/ashr_b16 + v_pk_mad_u16", out, clk);
     run<11>("v_cmp_e64 sgpr + s_nop 1 + v_cndmask_e64 (counted as 2)", out, clk);
     run_salu<0>("8 v_fma + 0 SALU", out, clk);
     run_salu<2>("8 v_fma + 4 SALU (interleaved)", out, clk);
