@@ -2,6 +2,7 @@
 // (the Python tests, other FFI users).  One call = one region = one rovaca::call_pairhmm invocation.
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <memory_resource>
 #include <vector>
 
@@ -87,6 +88,69 @@ int32_t rovaca_amd_call_region(const uint8_t *read_bases, const uint8_t *read_qu
         for (size_t k = 0; k < lik[h].size(); ++k) out_hap_read[h * n_reads + k] = lik[h][k];
     for (size_t k = 0; k < rs.size(); ++k) survivors[k] = (uint32_t)(rs[k] - reads.data());
     return (int32_t)rs.size();
+}
+
+// Several regions through the begin / finish form of the seam, `depth` of them in flight at a time (depth 1 = begin and finish
+// back to back = the synchronous call).  Reads and haplotypes of all regions are concatenated; region g owns reads
+// [region_read[g], region_read[g+1]) and haplotypes [region_hap[g], region_hap[g+1]).  out holds the matrices one after the
+// other ([n_haps][n_reads] each, tail NaN), survivors the surviving original read indices of each region at its read offset
+// (relative to the region), n_survivors[g] their number.  Returns 0, or -1 if the engine is not installed.
+int32_t rovaca_amd_call_regions_in_flight(const uint8_t *read_bases, const uint8_t *read_qual, const uint32_t *read_off,
+                                          const uint32_t *read_len, const uint8_t *read_mq, const uint8_t *hap_bases,
+                                          const uint32_t *hap_off, const uint32_t *hap_len, const uint32_t *region_read,
+                                          const uint32_t *region_hap, uint32_t n_regions, int32_t min_quality_threshold, int pcr_model,
+                                          uint32_t depth, double *out, uint32_t *survivors, uint32_t *n_survivors)
+{
+    using namespace rovaca;
+    if (!gpu_pairhmm_active()) return -1;
+    if (depth == 0) depth = 1;
+    struct InFlight
+    {
+        std::pmr::monotonic_buffer_resource arena;
+        std::vector<ReadRecord> reads;
+        std::vector<Haplotype> haps;
+        ReadVector rs{&arena};
+        HaplotypeVector hs{&arena};
+        PairhmmTicket ticket;
+        uint32_t region = 0;
+    };
+    std::vector<size_t> out_at(n_regions + 1, 0);
+    for (uint32_t g = 0; g < n_regions; ++g)
+        out_at[g + 1] = out_at[g] + (size_t)(region_read[g + 1] - region_read[g]) * (region_hap[g + 1] - region_hap[g]);
+    auto collect = [&](InFlight &f) {
+        const uint32_t g = f.region, r0 = region_read[g], nr = region_read[g + 1] - r0, nh = region_hap[g + 1] - region_hap[g];
+        DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(f.ticket), f.rs, &f.arena);
+        double *dst = out + out_at[g];
+        for (size_t k = 0; k < (size_t)nh * nr; ++k) dst[k] = NAN;
+        for (size_t h = 0; h < lik.size(); ++h)
+            for (size_t k = 0; k < lik[h].size(); ++k) dst[h * nr + k] = lik[h][k];
+        for (size_t k = 0; k < f.rs.size(); ++k) survivors[r0 + k] = (uint32_t)(f.rs[k] - f.reads.data());
+        n_survivors[g] = (uint32_t)f.rs.size();
+    };
+    std::vector<std::unique_ptr<InFlight>> ring(depth);
+    for (uint32_t g = 0; g < n_regions + depth - 1; ++g) {
+        std::unique_ptr<InFlight> &slot = ring[g % depth];
+        if (slot) {
+            collect(*slot);
+            slot.reset();
+        }
+        if (g < n_regions) {
+            slot.reset(new InFlight());
+            InFlight &f = *slot;
+            f.region = g;
+            f.reads.reserve(region_read[g + 1] - region_read[g]);
+            f.haps.reserve(region_hap[g + 1] - region_hap[g]);
+            for (uint32_t r = region_read[g]; r < region_read[g + 1]; ++r)
+                f.reads.emplace_back(read_bases + read_off[r], read_qual + read_off[r], read_len[r], read_mq[r]);
+            for (uint32_t h = region_hap[g]; h < region_hap[g + 1]; ++h) f.haps.emplace_back(hap_bases + hap_off[h], hap_len[h]);
+            for (auto &r : f.reads) f.rs.push_back(&r);
+            for (auto &h : f.haps) f.hs.push_back(&h);
+            f.ticket = call_gpu_pairhmm_begin(f.hs, f.rs, min_quality_threshold, static_cast<PcrIndelModel>(pcr_model));
+        }
+    }
+    for (auto &slot : ring)
+        if (slot) collect(*slot);
+    return 0;
 }
 
 }  // extern "C"

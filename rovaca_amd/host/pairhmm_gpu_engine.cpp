@@ -129,7 +129,8 @@ public:
         cv_.notify_all();
         worker_.join();
     }
-    int submit_and_wait(RegionJob &job)
+    // the job (and everything it points at) must stay alive until wait() has returned
+    void submit(RegionJob &job)
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -137,6 +138,9 @@ public:
             ++pending_;
         }
         if (dispatcher_sleeps_.load(std::memory_order_acquire)) cv_.notify_one();
+    }
+    int wait(RegionJob &job)
+    {
         if (!spin_until([&] { return job.done.load(std::memory_order_acquire); })) {
             std::unique_lock<std::mutex> lk(mu_);
             ++sleepers_;
@@ -144,6 +148,11 @@ public:
             --sleepers_;
         }
         return job.status;
+    }
+    int submit_and_wait(RegionJob &job)
+    {
+        submit(job);
+        return wait(job);
     }
     std::atomic<uint64_t> regions{0}, submissions{0};
 
@@ -318,89 +327,149 @@ void gpu_pairhmm_batching_stats(uint64_t *regions, uint64_t *submissions)
 
 bool gpu_pairhmm_active() { return g_active.load(); }
 
-DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32_t min_quality_threshold,
-                                PcrIndelModel pcr_option, pMemoryPool pool)
+// A region between call_gpu_pairhmm_begin and call_gpu_pairhmm_finish: the flattened tables the dispatcher reads, the
+// [read][hap] result it writes, and the job record.  Heap-allocated once per region; nothing in it refers to the caller's
+// vectors, so the caller may go on to its next region while this one is on the device.
+struct PairhmmTicket::State
 {
-    if (hs.empty() || rs.empty()) {
-        return {};
-    }
-    const size_t reads_num = rs.size();
-    const size_t haplotypes_num = hs.size();
-    // the result comes from the caller's arena, before anything else (pairhmm_internal.cpp:516)
-    DoubleVector2D final_likelihood{haplotypes_num, DoubleVector{reads_num, NAN, pool}, pool};
+    std::vector<uint32_t> read_off, read_len, hap_off, hap_len;
+    std::vector<int32_t> seq_len;
+    std::vector<uint8_t> bases, quals, mapq, hap_bases;
+    std::vector<double> likelihood;  // [read][hap]
+    size_t reads_num = 0, haplotypes_num = 0;
+    RegionJob job{};
+    RegionBatcher *batcher = nullptr;  // null: evaluated inside begin (batching off), `rc` / `why` hold the outcome
+    int rc = PHMM_OK;
+    char why[256] = "";
+};
+PairhmmTicket::PairhmmTicket() = default;
+PairhmmTicket::PairhmmTicket(PairhmmTicket &&) noexcept = default;
+PairhmmTicket &PairhmmTicket::operator=(PairhmmTicket &&) noexcept = default;
+PairhmmTicket::~PairhmmTicket()
+{
+    // a ticket dropped without finish: the dispatcher may still be writing into it
+    if (st_ && st_->batcher) st_->batcher->wait(st_->job);
+}
+
+PairhmmTicket call_gpu_pairhmm_begin(const HaplotypeVector &hs, const ReadVector &rs, int32_t min_quality_threshold, PcrIndelModel pcr_option)
+{
+    PairhmmTicket t;
+    if (hs.empty() || rs.empty()) return t;  // finish returns {} (pairhmm_internal.cpp:508-510)
+    t.st_.reset(new PairhmmTicket::State());
+    PairhmmTicket::State &st = *t.st_;
+    const size_t reads_num = st.reads_num = rs.size();
+    const size_t haplotypes_num = st.haplotypes_num = hs.size();
 
     // ---- flatten: read table ----
-    std::vector<uint32_t> read_off(reads_num), read_len(reads_num);
-    std::vector<int32_t> seq_len(reads_num);
+    st.read_off.resize(reads_num);
+    st.read_len.resize(reads_num);
+    st.seq_len.resize(reads_num);
     size_t total = 0;
     int32_t max_len = 0;
     for (size_t i = 0; i < reads_num; ++i) {
-        seq_len[i] = rs[i]->seq_length();
-        read_off[i] = (uint32_t)total;
-        read_len[i] = (uint32_t)seq_len[i];
-        total += (size_t)seq_len[i];
-        max_len = std::max(max_len, seq_len[i]);
+        st.seq_len[i] = rs[i]->seq_length();
+        st.read_off[i] = (uint32_t)total;
+        st.read_len[i] = (uint32_t)st.seq_len[i];
+        total += (size_t)st.seq_len[i];
+        max_len = std::max(max_len, st.seq_len[i]);
     }
     // H3 (quality modification) and H4 (PCR indel model) run on the device (phmm_read_prep); the host only gathers bytes
-    std::vector<uint8_t> bases(total), quals(total), mapq(reads_num);
+    st.bases.resize(total);
+    st.quals.resize(total);
+    st.mapq.resize(reads_num);
     std::vector<uint8_t> tmp(sizeof(Bases) + (size_t)max_len + 1);
     pBases read_bases = reinterpret_cast<pBases>(tmp.data());
     for (size_t i = 0; i < reads_num; ++i) {
         pReadRecord read = rs[i];
-        const uint32_t n = read_len[i], o = read_off[i];
+        const uint32_t n = st.read_len[i], o = st.read_off[i];
         read->decode_base(read_bases);
-        memcpy(bases.data() + o, read_bases->data, n);
-        memcpy(quals.data() + o, read->qual(), n);
-        mapq[i] = read->mapping_quality();
+        memcpy(st.bases.data() + o, read_bases->data, n);
+        memcpy(st.quals.data() + o, read->qual(), n);
+        st.mapq[i] = read->mapping_quality();
     }
     // ---- flatten: haplotype table ----
-    std::vector<uint32_t> hap_off(haplotypes_num), hap_len(haplotypes_num);
+    st.hap_off.resize(haplotypes_num);
+    st.hap_len.resize(haplotypes_num);
     size_t hap_total = 0;
     for (size_t j = 0; j < haplotypes_num; ++j) {
-        hap_off[j] = (uint32_t)hap_total;
-        hap_len[j] = hs[j]->get_display_string()->num;
-        hap_total += hap_len[j];
+        st.hap_off[j] = (uint32_t)hap_total;
+        st.hap_len[j] = hs[j]->get_display_string()->num;
+        hap_total += st.hap_len[j];
     }
-    std::vector<uint8_t> hap_bases(hap_total);
-    for (size_t j = 0; j < haplotypes_num; ++j) memcpy(hap_bases.data() + hap_off[j], hs[j]->get_display_string()->data, hap_len[j]);
+    st.hap_bases.resize(hap_total);
+    for (size_t j = 0; j < haplotypes_num; ++j)
+        memcpy(st.hap_bases.data() + st.hap_off[j], hs[j]->get_display_string()->data, st.hap_len[j]);
 
     // ---- the device: all reads x all haplotypes, (read, hap) order ----
-    std::vector<double> likelihood_array(reads_num * haplotypes_num);  // [read][hap]
+    st.likelihood.resize(reads_num * haplotypes_num);
     const int model = static_cast<int>(pcr_option);
-    int rc;
-    char why[256] = "";
     if (g_batching.load() && !g_batchers.empty()) {
-        RegionJob job{bases.data(), quals.data(), mapq.data(), hap_bases.data(), read_off.data(), read_len.data(),
-                      hap_off.data(), hap_len.data(), (uint32_t)reads_num, (uint32_t)haplotypes_num, total, hap_total,
-                      min_quality_threshold, model, likelihood_array.data()};
-        rc = g_batchers[g_next_batcher.fetch_add(1) % g_batchers.size()]->submit_and_wait(job);
-        if (rc != PHMM_OK) snprintf(why, sizeof(why), "%s", job.error);
+        RegionJob &job = st.job;
+        job.bases = st.bases.data();
+        job.quals = st.quals.data();
+        job.mapq = st.mapq.data();
+        job.hap_bases = st.hap_bases.data();
+        job.read_off = st.read_off.data();
+        job.read_len = st.read_len.data();
+        job.hap_off = st.hap_off.data();
+        job.hap_len = st.hap_len.data();
+        job.n_reads = (uint32_t)reads_num;
+        job.n_haps = (uint32_t)haplotypes_num;
+        job.read_bytes = total;
+        job.hap_bytes = hap_total;
+        job.min_q = min_quality_threshold;
+        job.pcr_model = model;
+        job.out = st.likelihood.data();
+        st.batcher = g_batchers[g_next_batcher.fetch_add(1) % g_batchers.size()];
+        st.batcher->submit(job);
     }
     else {
-        phmm_read_prep prep{mapq.data(), min_quality_threshold, model, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
+        phmm_read_prep prep{st.mapq.data(), min_quality_threshold, model, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
         phmm_batch b{};
         b.n_reads = (uint32_t)reads_num;
         b.n_haps = (uint32_t)haplotypes_num;
         b.n_pairs = (uint64_t)reads_num * haplotypes_num;
-        b.read_bases = bases.data();
-        b.read_qual = quals.data();
-        b.read_off = read_off.data();
-        b.read_len = read_len.data();
-        b.hap_bases = hap_bases.data();
-        b.hap_off = hap_off.data();
-        b.hap_len = hap_len.data();
+        b.read_bases = st.bases.data();
+        b.read_qual = st.quals.data();
+        b.read_off = st.read_off.data();
+        b.read_len = st.read_len.data();
+        b.hap_bases = st.hap_bases.data();
+        b.hap_off = st.hap_off.data();
+        b.hap_len = st.hap_len.data();
         b.prep = &prep;
-        rc = phmm_compute(t_ctx.get(), &b, nullptr, likelihood_array.data(), nullptr);
-        if (rc != PHMM_OK) snprintf(why, sizeof(why), "%s", phmm_last_error());
+        st.rc = phmm_compute(t_ctx.get(), &b, nullptr, st.likelihood.data(), nullptr);
+        if (st.rc != PHMM_OK) snprintf(st.why, sizeof(st.why), "%s", phmm_last_error());
     }
-    if (rc != PHMM_OK) {
-        fprintf(stderr, "[rovaca_amd] pairhmm: device evaluation failed (status %d): %s\n", rc, why);
+    return t;
+}
+
+DoubleVector2D call_gpu_pairhmm_finish(PairhmmTicket &&ticket, ReadVector &rs, pMemoryPool pool)
+{
+    PairhmmTicket t(std::move(ticket));
+    if (!t.st_) return {};
+    PairhmmTicket::State &st = *t.st_;
+    const size_t reads_num = st.reads_num, haplotypes_num = st.haplotypes_num;
+    if (rs.size() != reads_num) {
+        fprintf(stderr, "[rovaca_amd] pairhmm: call_gpu_pairhmm_finish was handed a read list of %zu reads for a region begun with %zu\n",
+                rs.size(), reads_num);
+        exit(EXIT_FAILURE);
+    }
+    // the result comes from the caller's arena (pairhmm_internal.cpp:516)
+    DoubleVector2D final_likelihood{haplotypes_num, DoubleVector{reads_num, NAN, pool}, pool};
+    if (st.batcher) {
+        st.rc = st.batcher->wait(st.job);
+        if (st.rc != PHMM_OK) snprintf(st.why, sizeof(st.why), "%s", st.job.error);
+        st.batcher = nullptr;  // nothing of the ticket is in flight any more
+    }
+    if (st.rc != PHMM_OK) {
+        fprintf(stderr, "[rovaca_amd] pairhmm: device evaluation failed (status %d): %s\n", st.rc, st.why);
         exit(EXIT_FAILURE);
     }
 
     // ---- post-processing (pairhmm_internal.cpp:589-591) ----
-    rovaca_amd::normalize_likelihoods(likelihood_array.data(), reads_num, haplotypes_num);
-    const std::vector<size_t> drop = rovaca_amd::poorly_modelled_reads(likelihood_array.data(), seq_len.data(), reads_num, haplotypes_num);
+    double *likelihood_array = st.likelihood.data();
+    rovaca_amd::normalize_likelihoods(likelihood_array, reads_num, haplotypes_num);
+    const std::vector<size_t> drop = rovaca_amd::poorly_modelled_reads(likelihood_array, st.seq_len.data(), reads_num, haplotypes_num);
     std::vector<char> dropped(reads_num, 0);
     for (size_t r : drop) dropped[r] = 1;
     for (auto it = drop.rbegin(); it != drop.rend(); ++it) rs.erase(rs.begin() + (std::ptrdiff_t)*it);  // back to front, :178-181
@@ -411,6 +480,13 @@ DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32
         ++k;
     }
     return final_likelihood;
+}
+
+DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32_t min_quality_threshold,
+                                PcrIndelModel pcr_option, pMemoryPool pool)
+{
+    // the synchronous seam (pairhmm_engine.h:14-15) is begin + finish back to back
+    return call_gpu_pairhmm_finish(call_gpu_pairhmm_begin(hs, rs, min_quality_threshold, pcr_option), rs, pool);
 }
 
 DoubleVector2D marginal_likelihoods_direct(const DoubleVector2D &old_sample_values, size_t evidence_count, size_t new_allele_count,

@@ -7,6 +7,8 @@
 #ifndef ROVACA_AMD_PAIRHMM_GPU_ENGINE_H_
 #define ROVACA_AMD_PAIRHMM_GPU_ENGINE_H_
 
+#include <memory>
+
 #ifdef ROVACA_AMD_IN_ROVACA_TREE
 #include "../common/enum.h"
 #include "../genotype/forward.h"
@@ -27,6 +29,31 @@ namespace rovaca
 //     context (stream + staging) on first use.
 DoubleVector2D call_gpu_pairhmm(const HaplotypeVector &hs, ReadVector &rs, int32_t min_quality_threshold,
                                 PcrIndelModel pcr_option, pMemoryPool pool);
+
+// The same evaluation in two halves ("... one GPU submission; return futures").  begin flattens the region,
+// hands it to the cross-region batcher and returns at once; finish waits for it, runs H8 (normalise, filter, transpose) and
+// returns what call_gpu_pairhmm returns -- begin + finish back to back IS call_gpu_pairhmm.  In between the worker is free:
+// with the next region's begin issued before this region's finish, a worker keeps two regions in flight and the device sees
+// batches twice as large (tools/adapter_bench.cpp measures both forms; INTEGRATION.md shows the caller-side loop).  The
+// ticket owns copies of everything the device reads; `rs` handed to finish must be the list begin saw (it is shrunk there).
+// A ticket that is destroyed without finish waits for its region and discards it.
+class PairhmmTicket
+{
+public:
+    PairhmmTicket();
+    PairhmmTicket(PairhmmTicket &&) noexcept;
+    PairhmmTicket &operator=(PairhmmTicket &&) noexcept;
+    ~PairhmmTicket();
+    explicit operator bool() const { return st_ != nullptr; }  // false: an empty region (finish returns {})
+    struct State;
+
+private:
+    std::unique_ptr<State> st_;
+    friend PairhmmTicket call_gpu_pairhmm_begin(const HaplotypeVector &, const ReadVector &, int32_t, PcrIndelModel);
+    friend DoubleVector2D call_gpu_pairhmm_finish(PairhmmTicket &&, ReadVector &, pMemoryPool);
+};
+PairhmmTicket call_gpu_pairhmm_begin(const HaplotypeVector &hs, const ReadVector &rs, int32_t min_quality_threshold, PcrIndelModel pcr_option);
+DoubleVector2D call_gpu_pairhmm_finish(PairhmmTicket &&ticket, ReadVector &rs, pMemoryPool pool);
 
 // Mirrors the seam's global: what haplotypecaller_engine.cpp:250 calls.
 extern DoubleVector2D (*call_pairhmm)(const HaplotypeVector &hs, ReadVector &rs, int32_t min_quality_threshold,

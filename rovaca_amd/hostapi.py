@@ -83,6 +83,50 @@ def call_region(read_bases, read_qual, read_off, read_len, read_mq, hap_bases, h
     return out, surv[:n].copy()
 
 
+def call_regions_in_flight(regions, depth, min_quality_threshold=18, pcr_model="CONSERVATIVE"):
+    """Several regions through the begin/finish form of the seam, ``depth`` in flight at a time.  ``regions``: a list of
+    (read_bases, read_qual, read_off, read_len, read_mq, hap_bases, hap_off, hap_len) as for call_region.  Returns a list of
+    (matrix [n_haps][n_reads], survivors) in the same order."""
+    L = lib()
+    rb, rq, ro, rl, mq, hb, ho, hl, rr, rh = [], [], [], [], [], [], [], [], [0], [0]
+    rbytes = hbytes = 0
+    for (b, q, off, ln, m, hbs, hof, hln) in regions:
+        b, q, hbs = (np.ascontiguousarray(x, np.uint8) for x in (b, q, hbs))
+        rb.append(b)
+        rq.append(q)
+        ro.append(np.asarray(off, np.uint32) + rbytes)
+        rl.append(np.asarray(ln, np.uint32))
+        mq.append(np.asarray(m, np.uint8))
+        hb.append(hbs)
+        ho.append(np.asarray(hof, np.uint32) + hbytes)
+        hl.append(np.asarray(hln, np.uint32))
+        rbytes += len(b)
+        hbytes += len(hbs)
+        rr.append(rr[-1] + len(ln))
+        rh.append(rh[-1] + len(hln))
+    cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(0, dt), dt)
+    rr, rh = np.asarray(rr, np.uint32), np.asarray(rh, np.uint32)
+    sizes = [(int(rh[g + 1] - rh[g]), int(rr[g + 1] - rr[g])) for g in range(len(regions))]
+    out = np.full(max(1, sum(a * b for a, b in sizes)), np.nan)
+    surv = np.zeros(max(1, int(rr[-1])), np.uint32)
+    nsurv = np.zeros(max(1, len(regions)), np.uint32)
+    f = L.rovaca_amd_call_regions_in_flight
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p] * 10 + [C.c_uint32, C.c_int32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    arrs = [cat(rb, np.uint8), cat(rq, np.uint8), cat(ro, np.uint32), cat(rl, np.uint32), cat(mq, np.uint8), cat(hb, np.uint8),
+            cat(ho, np.uint32), cat(hl, np.uint32), rr, rh]
+    rc = f(*[ptr(a) for a in arrs], len(regions), int(min_quality_threshold),
+           PCR[pcr_model] if isinstance(pcr_model, str) else int(pcr_model), int(depth), ptr(out), ptr(surv), ptr(nsurv))
+    if rc != 0:
+        raise RuntimeError("the MI355X engine is not installed: init_pairhmm_ptr_gpu() found no device")
+    res, at = [], 0
+    for g, (nh, nr) in enumerate(sizes):
+        res.append((out[at:at + nh * nr].reshape(nh, nr).copy(), surv[int(rr[g]):int(rr[g]) + int(nsurv[g])].copy()))
+        at += nh * nr
+    return res
+
+
 def marginal_likelihoods_direct(old, old2new, n_new, evidence_count=None, through_adapter=False):
     """old: [n_old][stride] doubles; returns [n_new][evidence_count] (allele_likelihoods.hpp:702-732, one sample).
     through_adapter: go through rovaca::marginal_likelihoods_direct (pmr vectors) instead of the flat routine."""

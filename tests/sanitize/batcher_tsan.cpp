@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <memory_resource>
 #include <random>
 #include <thread>
@@ -92,14 +93,25 @@ int main()
     if (!init_pairhmm_ptr_gpu(0)) return 2;
     const int threads = 12, per_thread = 40;
     std::atomic<int> bad{0};
-    auto work = [&](int t) {
-        std::mt19937 rng(100 + t);
-        const char acgt[] = "ACGT";
-        for (int k = 0; k < per_thread; ++k) {
-            const int n_reads = 1 + rng() % 12, n_haps = 1 + rng() % 5;
-            std::vector<ReadRecord> reads;
-            std::vector<Haplotype> haps;
-            std::vector<std::vector<uint8_t>> rb(n_reads), hb(n_haps);
+    struct RegionData  // one synthetic region and everything that must outlive its evaluation
+    {
+        int n_reads = 0, n_haps = 0;
+        std::vector<ReadRecord> reads;
+        std::vector<Haplotype> haps;
+        std::vector<std::vector<uint8_t>> rb, hb;
+        std::pmr::monotonic_buffer_resource arena;
+        ReadVector rs{&arena};
+        HaplotypeVector hs{&arena};
+        PairhmmTicket ticket;
+        explicit RegionData(std::mt19937 &rng)
+        {
+            const char acgt[] = "ACGT";
+            n_reads = 1 + rng() % 12;
+            n_haps = 1 + rng() % 5;
+            rb.resize(n_reads);
+            hb.resize(n_haps);
+            reads.reserve(n_reads);
+            haps.reserve(n_haps);
             for (auto &h : hb) {
                 h.resize(60 + rng() % 100);
                 for (auto &c : h) c = acgt[rng() & 3];
@@ -111,21 +123,46 @@ int main()
                 std::vector<uint8_t> q(r.size(), 30);
                 reads.emplace_back(r.data(), q.data(), (uint32_t)r.size(), (uint8_t)60);
             }
-            std::pmr::monotonic_buffer_resource arena;
-            ReadVector rs{&arena};
-            HaplotypeVector hs{&arena};
             for (auto &r : reads) rs.push_back(&r);
             for (auto &h : haps) hs.push_back(&h);
-            DoubleVector2D lik = call_pairhmm(hs, rs, 18, PcrIndelModel::NONE, &arena);
-            // every surviving read's row must be this region's own numbers (normalisation only caps from below)
+        }
+        // every surviving read's row must be this region's own numbers (normalisation only caps from below)
+        int mismatches(const DoubleVector2D &lik) const
+        {
+            int n = 0;
             for (size_t r = 0; r < rs.size(); ++r) {
                 const size_t orig = (size_t)(rs[r] - reads.data());
                 double best = -1e300;
                 for (int h = 0; h < n_haps; ++h) best = std::max(best, fake_likelihood(rb[orig].data(), (uint32_t)rb[orig].size(), hb[h].data(), (uint32_t)hb[h].size()));
                 for (int h = 0; h < n_haps; ++h) {
                     const double want = std::max(fake_likelihood(rb[orig].data(), (uint32_t)rb[orig].size(), hb[h].data(), (uint32_t)hb[h].size()), best - 4.5);
-                    if (lik[h][r] != want) ++bad;
+                    if (lik[h][r] != want) ++n;
                 }
+            }
+            return n;
+        }
+    };
+    auto work = [&](int t) {
+        std::mt19937 rng(100 + t);
+        std::unique_ptr<RegionData> in_flight;  // odd workers: the begin / finish form, the previous region still on the "device"
+        auto collect = [&](RegionData &rg) {
+            DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(rg.ticket), rg.rs, &rg.arena);
+            bad += rg.mismatches(lik);
+        };
+        for (int k = 0; k < per_thread; ++k) {
+            std::unique_ptr<RegionData> cur(new RegionData(rng));
+            RegionData &rg = *cur;
+            const int n_reads = rg.n_reads, n_haps = rg.n_haps;
+            auto &rb = rg.rb;
+            auto &hb = rg.hb;
+            if (t & 1) {
+                rg.ticket = call_gpu_pairhmm_begin(rg.hs, rg.rs, 18, PcrIndelModel::NONE);
+                if (in_flight) collect(*in_flight);
+                in_flight = std::move(cur);
+            }
+            else {
+                DoubleVector2D lik = call_pairhmm(rg.hs, rg.rs, 18, PcrIndelModel::NONE, &rg.arena);
+                bad += rg.mismatches(lik);
             }
             // Smith-Waterman batcher: one request per region
             std::vector<SwJob> jobs;
@@ -138,6 +175,12 @@ int main()
                 if (aln[r].cigar.size() != 1 || aln[r].cigar[0] != (((uint32_t)rb[r].size() << 4) | 0u)) ++bad;
             }
         }
+        if (in_flight) collect(*in_flight);
+        // a ticket dropped without finish must wait for its region and let go of it quietly
+        if (t & 1) {
+            RegionData rg(rng);
+            rg.ticket = call_gpu_pairhmm_begin(rg.hs, rg.rs, 18, PcrIndelModel::NONE);
+        }
     };
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
@@ -147,7 +190,7 @@ int main()
     sw_hip_batching_stats(&rq, &sw_subs);
     printf("batchers: %llu regions in %llu submissions, %llu alignment requests in %llu submissions, %d mismatches\n",
            (unsigned long long)regions, (unsigned long long)subs, (unsigned long long)rq, (unsigned long long)sw_subs, bad.load());
-    if (bad.load() || regions != (uint64_t)threads * per_thread || subs >= regions || sw_subs >= rq) return 1;
+    if (bad.load() || regions != (uint64_t)threads * per_thread + threads / 2 || subs >= regions || sw_subs >= rq) return 1;
     fflush(stdout);
     _Exit(0);  // the dispatcher threads are never joined (by design); leave without static teardown
 }

@@ -71,6 +71,26 @@ def test_concurrent_workers():
         assert np.array_equal(sa, sb) and np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize("depth", [1, 2, 5])
+def test_begin_finish_form_keeps_regions_in_flight(depth):
+    # SURVEY.md 8f next-1 ("return futures"): call_gpu_pairhmm_begin hands a region to the batcher, call_gpu_pairhmm_finish
+    # collects it; with `depth` regions in flight per worker the results are those of the synchronous call, region by region,
+    # reads dropped by H8 and empty regions included
+    regions = [_raw_region(70 + i, reads=6 + 5 * (i % 7), haps=2 + i % 6, read_len=(40, 150), hap_len=200 + 17 * i,
+                           bad_reads=(i % 3)) for i in range(14)]
+    e8, e32 = np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+    regions.insert(5, (e8, e8, e32, e32, e8, regions[0][5], regions[0][6], regions[0][7]))  # a region without reads -> {}
+    single = [hostapi.call_region(*r) for r in regions]
+    r0, s0 = hostapi.batching_stats()
+    got = hostapi.call_regions_in_flight(regions, depth)
+    r1, s1 = hostapi.batching_stats()
+    assert len(got) == len(regions)
+    for (a, sa), (b, sb) in zip(single, got):
+        assert a.shape == b.shape and np.array_equal(sa, sb) and np.array_equal(a, b, equal_nan=True)
+    assert r1 - r0 == len(regions) - 1  # the empty region never reaches the device
+    assert s1 - s0 <= r1 - r0  # (whether one worker's regions share a submission depends on which dispatcher is free)
+
+
 def test_cross_region_batching_coalesces_concurrent_workers():
     # 32 workers x 8 regions each; the dispatcher must merge concurrent submissions into fewer
     # device batches and every worker must still get exactly its own region's matrix

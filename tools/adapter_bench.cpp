@@ -1,12 +1,14 @@
 // adapter_bench.cpp -- end-to-end throughput of the drop-in adapter: N worker threads call rovaca::call_pairhmm on
 // synthetic regions (as haplotypecaller_engine.cpp:119-285 does from its asio pool), through the cross-region batcher.
-// Build: make -C rovaca_amd/host bench   Run on the GPU box: rovaca_amd/lib/adapter_bench [threads] [regions/thread] [reads] [haps] [sw]
+// Build: make -C rovaca_amd/host bench   Run on the GPU box: rovaca_amd/lib/adapter_bench [threads] [regions/thread] [reads] [haps] [sw] [regions in flight per worker]
 // sw = 1: after PairHMM every surviving read is realigned to its best haplotype through rovaca::sw_hip_align_batch
 // (haplotypecaller_engine.cpp:264), one call per region.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <memory_resource>
 #include <random>
 #include <thread>
@@ -55,6 +57,7 @@ int main(int argc, char **argv)
     const int threads = argc > 1 ? atoi(argv[1]) : 30, per_thread = argc > 2 ? atoi(argv[2]) : 64;
     const int n_reads = argc > 3 ? atoi(argv[3]) : 48, n_haps = argc > 4 ? atoi(argv[4]) : 9;
     const bool with_sw = argc > 5 && atoi(argv[5]) != 0;
+    const int depth = argc > 6 ? std::max(1, atoi(argv[6])) : 1;  // regions a worker keeps in flight (begin/finish form of the seam)
     if (!init_pairhmm_ptr_gpu(0)) {
         fprintf(stderr, "no MI355X visible\n");
         return 2;
@@ -62,15 +65,8 @@ int main(int argc, char **argv)
     std::vector<Region> regions;
     for (int i = 0; i < 16; ++i) regions.push_back(make_region(1000 + i, n_reads, n_haps, 150, 300));
     std::atomic<uint64_t> cells{0}, kept{0}, sw_cells{0}, sw_elems{0};
-    auto work = [&](int t) {
-        for (int k = 0; k < per_thread; ++k) {
-            Region &rg = regions[(t + k) % regions.size()];
-            std::pmr::monotonic_buffer_resource arena;
-            ReadVector rs{&arena};
-            HaplotypeVector hs{&arena};
-            for (auto &r : rg.reads) rs.push_back(&r);
-            for (auto &h : rg.haps) hs.push_back(&h);
-            DoubleVector2D lik = call_pairhmm(hs, rs, 18, PcrIndelModel::CONSERVATIVE, &arena);
+    // what follows the seam in the caller (haplotypecaller_engine.cpp:250-285), as far as this benchmark goes
+    auto after_pairhmm = [&](Region &rg, HaplotypeVector &hs, ReadVector &rs, DoubleVector2D &lik) {
             cells += rg.cells;
             kept += rs.size();
             if (with_sw && !rs.empty()) {
@@ -92,7 +88,53 @@ int main(int argc, char **argv)
                 if (!sw_hip_align_batch(jobs.data(), jobs.size(), genotype, aln)) exit(3);
                 sw_elems += aln.empty() ? 0 : aln[0].cigar.size();
             }
+    };
+    struct InFlight
+    {
+        std::pmr::monotonic_buffer_resource arena;
+        ReadVector rs{&arena};
+        HaplotypeVector hs{&arena};
+        Region *rg = nullptr;
+        PairhmmTicket ticket;
+    };
+    auto work = [&](int t) {
+        if (depth <= 1) {  // the seam as the reference calls it: one region at a time, synchronously
+            for (int k = 0; k < per_thread; ++k) {
+                Region &rg = regions[(t + k) % regions.size()];
+                std::pmr::monotonic_buffer_resource arena;
+                ReadVector rs{&arena};
+                HaplotypeVector hs{&arena};
+                for (auto &r : rg.reads) rs.push_back(&r);
+                for (auto &h : rg.haps) hs.push_back(&h);
+                DoubleVector2D lik = call_pairhmm(hs, rs, 18, PcrIndelModel::CONSERVATIVE, &arena);
+                after_pairhmm(rg, hs, rs, lik);
+            }
+            return;
         }
+        // begin/finish: region k + depth - 1 is handed to the device before region k is collected
+        std::vector<std::unique_ptr<InFlight>> ring(depth);
+        for (int k = 0; k < per_thread + depth - 1; ++k) {
+            std::unique_ptr<InFlight> &slot = ring[k % depth];
+            if (slot) {
+                {
+                    DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(slot->ticket), slot->rs, &slot->arena);
+                    after_pairhmm(*slot->rg, slot->hs, slot->rs, lik);
+                }  // the matrix lives in the slot's arena: gone before the arena is
+                slot.reset();
+            }
+            if (k < per_thread) {
+                slot.reset(new InFlight());
+                slot->rg = &regions[(t + k) % regions.size()];
+                for (auto &r : slot->rg->reads) slot->rs.push_back(&r);
+                for (auto &h : slot->rg->haps) slot->hs.push_back(&h);
+                slot->ticket = call_gpu_pairhmm_begin(slot->hs, slot->rs, 18, PcrIndelModel::CONSERVATIVE);
+            }
+        }
+        for (auto &slot : ring)
+            if (slot) {
+                DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(slot->ticket), slot->rs, &slot->arena);
+                after_pairhmm(*slot->rg, slot->hs, slot->rs, lik);
+            }
     };
     work(0);  // warm up: contexts, tables, kernels
     cells = 0;
@@ -106,8 +148,8 @@ int main(int argc, char **argv)
     gpu_pairhmm_batching_stats(&nreg, &nsub);
     printf("{\"threads\": %d, \"regions\": %d, \"reads_per_region\": %d, \"haps_per_region\": %d, \"seconds\": %.4f, "
            "\"regions_per_s\": %.0f, \"gcups_end_to_end\": %.1f, \"device_submissions\": %llu, \"regions_per_submission\": %.1f, "
-           "\"smith_waterman\": %s, \"sw_gcups_end_to_end\": %.1f}\n",
+           "\"smith_waterman\": %s, \"sw_gcups_end_to_end\": %.1f, \"regions_in_flight_per_worker\": %d}\n",
            threads, threads * per_thread, n_reads, n_haps, sec, threads * per_thread / sec, cells.load() / sec / 1e9,
-           (unsigned long long)nsub, nsub ? (double)nreg / nsub : 0.0, with_sw ? "true" : "false", sw_cells.load() / sec / 1e9);
+           (unsigned long long)nsub, nsub ? (double)nreg / nsub : 0.0, with_sw ? "true" : "false", sw_cells.load() / sec / 1e9, depth);
     return 0;
 }
