@@ -207,12 +207,18 @@ class Engine:
         _check(L.phmm_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)), "phmm_create")
         self.handle = h
 
-    def compute(self, batch, cross=False, prep=None):
-        """Host buffers in, (raw_f32, log10, stats) out."""
+    def compute(self, batch, cross=False, prep=None, out=None):
+        """Host buffers in, (raw_f32, log10, stats) out.  ``out``: (raw float32[n], log10 float64[n]) to write into -- a caller
+        that evaluates batch after batch keeps its result buffers, as the C++ adapter does; fresh arrays are made otherwise."""
         cb = _c_batch(batch, cross, prep)
         n = batch.n_reads * batch.n_haps if cross else batch.n_pairs
-        raw = np.zeros(n, np.float32)
-        l10 = np.zeros(n, np.float64)
+        if out is not None:
+            raw, l10 = out
+            assert raw.dtype == np.float32 and l10.dtype == np.float64 and raw.size >= n and l10.size >= n
+            assert raw.flags.c_contiguous and l10.flags.c_contiguous
+        else:
+            raw = np.zeros(n, np.float32)
+            l10 = np.zeros(n, np.float64)
         st = PhmmStats()
         _check(lib().phmm_compute(self.handle, C.byref(cb), _ptr(raw), _ptr(l10), C.byref(st)), "phmm_compute")
         return raw, l10, st
