@@ -87,6 +87,29 @@ class Batch:
                      meta=dict(self.meta))
 
     @staticmethod
+    def concat(parts):
+        """One batch out of several: tables laid end to end, offsets and pair indices rebased (region structure kept when
+        every part has one)."""
+        parts = list(parts)
+        if len(parts) == 1:
+            return parts[0]
+        rbytes = np.cumsum([0] + [p.read_bases.shape[0] for p in parts])
+        hbytes = np.cumsum([0] + [p.hap_bases.shape[0] for p in parts])
+        nr = np.cumsum([0] + [p.n_reads for p in parts])
+        nh = np.cumsum([0] + [p.n_haps for p in parts])
+        npairs = np.cumsum([0] + [p.n_pairs for p in parts])
+        assert rbytes[-1] < 2 ** 32 and hbytes[-1] < 2 ** 32
+        cat = lambda k: np.concatenate([getattr(p, k) for p in parts])
+        shifted = lambda k, base: np.concatenate([getattr(p, k).astype(np.int64) + int(base[i]) for i, p in enumerate(parts)])
+        regions = all(p.region_read is not None for p in parts)
+        tail = lambda k, base: np.concatenate([[0]] + [getattr(p, k)[1:].astype(np.int64) + int(base[i]) for i, p in enumerate(parts)])
+        return Batch(cat("read_bases"), cat("read_qual"), cat("read_ins"), cat("read_del"), cat("read_gcp"),
+                     shifted("read_off", rbytes), cat("read_len"), cat("hap_bases"), shifted("hap_off", hbytes), cat("hap_len"),
+                     shifted("pair_read", nr), shifted("pair_hap", nh),
+                     region_read=tail("region_read", nr) if regions else None, region_hap=tail("region_hap", nh) if regions else None,
+                     region_pair=tail("region_pair", npairs) if regions else None, meta=dict(parts[0].meta, concatenated=len(parts)))
+
+    @staticmethod
     def from_lists(reads, haps, pairs=None):
         """reads: list of (bases, qual, ins, del, gcp) byte-likes; haps: list of byte-likes; pairs: list of
         (read_idx, hap_idx) or None for the full cross product in (read, hap) order."""
