@@ -380,7 +380,10 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
 // and sensitive to any change of its text ("Register numbers matter").
 // ----------------------------------------------------------------------------------------------------
 template <typename T, int K, int G>
-__global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHMM_MIN_WAVES(T, K, true))
+// occupancy targets of this kernel, measured per K (tools/bench_by_k.py): it has 2K - 1 fewer live registers than the general one, so
+// K = 12 still fits four waves (+1 %) and K = 15 three (5 670 -> 6 050 GCUPS); K = 16 at three waves spills inside the loop (4 980)
+#define PHMM_UGO_MIN_WAVES(T, K) (sizeof(T) == 8 ? 2 : (K) <= 12 ? 4 : (K) <= 15 ? 3 : 1)
+__global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHMM_UGO_MIN_WAVES(T, K))
     pairhmm_systolic_ugo_kernel(KernelArgs a)
 {
     extern __shared__ uint32_t lds[];
