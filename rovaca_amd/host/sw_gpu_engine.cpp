@@ -125,16 +125,25 @@ class SwBatcher
 {
 public:
     SwBatcher() : worker_([this] { run(); }) {}
-    bool submit_and_wait(Request &rq)
+    // the request (and what it points at) must stay alive until wait() has returned
+    void submit(Request &rq)
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
             queue_.push_back(&rq);
         }
         cv_.notify_one();
+    }
+    bool wait(Request &rq)
+    {
         std::unique_lock<std::mutex> lk(mu_);
         done_cv_.wait(lk, [&] { return rq.done.load(std::memory_order_acquire); });
         return rq.ok;
+    }
+    bool submit_and_wait(Request &rq)
+    {
+        submit(rq);
+        return wait(rq);
     }
     std::atomic<uint64_t> requests{0}, submissions{0};
 
@@ -224,6 +233,61 @@ bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, 
     if (g_sw_batchers.empty()) return align_now(jobs, n, para, out.data());
     Request rq{jobs, n, para, out.data()};
     return g_sw_batchers[g_sw_next.fetch_add(1) % g_sw_batchers.size()]->submit_and_wait(rq);
+}
+
+// The same call in two halves, as for PairHMM (pairhmm_gpu_engine.h): begin queues the alignments and returns, finish collects.
+struct SwTicket::State
+{
+    std::vector<SwJob> jobs;  // the job records are copied; the sequence bytes they point at stay the caller's
+    std::vector<SwAlignment> out;
+    sw_parameters para{};
+    Request rq{nullptr, 0, sw_parameters{}, nullptr};
+    SwBatcher *batcher = nullptr;  // null: evaluated inside begin (batching off)
+    bool ok = true;
+};
+SwTicket::SwTicket() = default;
+SwTicket::SwTicket(SwTicket &&) noexcept = default;
+SwTicket &SwTicket::operator=(SwTicket &&) noexcept = default;
+SwTicket::~SwTicket()
+{
+    if (st_ && st_->batcher) st_->batcher->wait(st_->rq);  // dropped without finish: the dispatcher may still be writing into it
+}
+
+SwTicket sw_hip_align_batch_begin(const SwJob *jobs, size_t n, const sw_parameters &para)
+{
+    SwTicket t;
+    if (n == 0) return t;
+    t.st_.reset(new SwTicket::State());
+    SwTicket::State &st = *t.st_;
+    st.jobs.assign(jobs, jobs + n);
+    st.out.assign(n, SwAlignment{});
+    st.para = para;
+    std::call_once(g_sw_once, start_batchers);
+    if (g_sw_batchers.empty()) {
+        st.ok = align_now(st.jobs.data(), n, para, st.out.data());
+        return t;
+    }
+    st.rq.jobs = st.jobs.data();
+    st.rq.n = n;
+    st.rq.para = para;
+    st.rq.out = st.out.data();
+    st.batcher = g_sw_batchers[g_sw_next.fetch_add(1) % g_sw_batchers.size()];
+    st.batcher->submit(st.rq);
+    return t;
+}
+
+bool sw_hip_align_batch_finish(SwTicket &&ticket, std::vector<SwAlignment> &out)
+{
+    SwTicket t(std::move(ticket));
+    out.clear();
+    if (!t.st_) return true;
+    SwTicket::State &st = *t.st_;
+    if (st.batcher) {
+        st.ok = st.batcher->wait(st.rq);
+        st.batcher = nullptr;
+    }
+    out = std::move(st.out);
+    return st.ok;
 }
 
 void sw_hip_batching_stats(uint64_t *requests, uint64_t *submissions)
@@ -324,6 +388,59 @@ int rovaca_amd_sw_run_through_handle(const uint8_t *seq1, int32_t len1, const ui
     for (uint32_t k = 0; k < p->cigar_count && k < cigar_cap; ++k) cigar[k] = p->cigar[k];
     free(p);
     return 0;
+}
+
+// Test shim for the two-halves form: alignments k in [batch_start[g], batch_start[g+1]) form request g; `depth` requests are in
+// flight at a time.  Alignment k is ref_bytes[ref_off[k] .. +ref_len[k]) against seq_bytes[seq_off[k] .. +seq_len[k]).  Results: result[k] =
+// {score, max_i, max_j, alignment_offset, too_long, cigar_count}; the CIGAR of alignment k is written at cigars[cigar_at[k] ..).
+// Returns 0, or -1 on a device error.
+int rovaca_amd_sw_batches_in_flight(const uint8_t *ref_bytes, const uint32_t *ref_off, const uint32_t *ref_len, const uint8_t *seq_bytes,
+                                    const uint32_t *seq_off, const uint32_t *seq_len, const uint32_t *batch_start, uint32_t n_batches,
+                                    int is_assemble, uint32_t depth, int32_t *result, uint32_t *cigars, const uint32_t *cigar_at)
+{
+    using namespace rovaca;
+    const sw_parameters para = is_assemble ? sw_parameters{200, -150, -260, -11} : sw_parameters{10, -15, -30, -5};
+    if (depth == 0) depth = 1;
+    struct InFlight
+    {
+        uint32_t batch = 0;
+        SwTicket ticket;
+    };
+    int rc = 0;
+    auto collect = [&](InFlight &f) {
+        std::vector<SwAlignment> aln;
+        if (!sw_hip_align_batch_finish(std::move(f.ticket), aln)) rc = -1;
+        const uint32_t k0 = batch_start[f.batch];
+        for (size_t a = 0; a < aln.size(); ++a) {
+            int32_t *r = result + 6 * (size_t)(k0 + a);
+            r[0] = aln[a].score;
+            r[1] = aln[a].max_i;
+            r[2] = aln[a].max_j;
+            r[3] = aln[a].alignment_offset;
+            r[4] = aln[a].too_long ? 1 : 0;
+            r[5] = (int32_t)aln[a].cigar.size();
+            for (size_t c = 0; c < aln[a].cigar.size(); ++c) cigars[cigar_at[k0 + a] + c] = aln[a].cigar[c];
+        }
+    };
+    std::deque<InFlight> q;
+    for (uint32_t g = 0; g < n_batches; ++g) {
+        std::vector<SwJob> jobs;
+        for (uint32_t k = batch_start[g]; k < batch_start[g + 1]; ++k)
+            jobs.push_back(SwJob{ref_bytes + ref_off[k], (int32_t)ref_len[k], seq_bytes + seq_off[k], (int32_t)seq_len[k]});
+        InFlight f;
+        f.batch = g;
+        f.ticket = sw_hip_align_batch_begin(jobs.data(), jobs.size(), para);  // the job records are copied: `jobs` may go
+        q.push_back(std::move(f));
+        if (q.size() >= depth) {
+            collect(q.front());
+            q.pop_front();
+        }
+    }
+    while (!q.empty()) {
+        collect(q.front());
+        q.pop_front();
+    }
+    return rc;
 }
 
 }  // extern "C"

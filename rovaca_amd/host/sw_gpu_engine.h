@@ -19,6 +19,7 @@
 
 #ifdef __cplusplus
 #include <cstddef>
+#include <memory>
 #include <vector>
 
 extern "C" {
@@ -64,6 +65,27 @@ struct SwAlignment
 // of dispatcher threads, as for PairHMM; ROVACA_AMD_SW_BATCHING=0 makes every caller use its own device context instead.
 // Returns false on a device error (text on stderr).
 bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, std::vector<SwAlignment> &out);
+// The same in two halves: begin queues the alignments with the dispatchers and returns at once, finish waits and hands the results
+// over -- begin + finish back to back is sw_hip_align_batch.  A worker can thus have a region's realignment on the device while it
+// prepares the next region (tools/adapter_bench.cpp).  The job records are copied; the sequence bytes they point at must stay valid
+// until finish.  A ticket destroyed without finish waits for its alignments and drops them.
+class SwTicket
+{
+public:
+    SwTicket();
+    SwTicket(SwTicket &&) noexcept;
+    SwTicket &operator=(SwTicket &&) noexcept;
+    ~SwTicket();
+    explicit operator bool() const { return st_ != nullptr; }
+    struct State;
+
+private:
+    std::unique_ptr<State> st_;
+    friend SwTicket sw_hip_align_batch_begin(const SwJob *, size_t, const sw_parameters &);
+    friend bool sw_hip_align_batch_finish(SwTicket &&, std::vector<SwAlignment> &);
+};
+SwTicket sw_hip_align_batch_begin(const SwJob *jobs, size_t n, const sw_parameters &para);
+bool sw_hip_align_batch_finish(SwTicket &&ticket, std::vector<SwAlignment> &out);
 // requests served and device calls made by the dispatchers
 void sw_hip_batching_stats(uint64_t *requests, uint64_t *submissions);
 

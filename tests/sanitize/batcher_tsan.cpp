@@ -103,6 +103,7 @@ int main()
         ReadVector rs{&arena};
         HaplotypeVector hs{&arena};
         PairhmmTicket ticket;
+        SwTicket sw_ticket;  // destroyed before the sequences it points at
         explicit RegionData(std::mt19937 &rng)
         {
             const char acgt[] = "ACGT";
@@ -145,9 +146,24 @@ int main()
     auto work = [&](int t) {
         std::mt19937 rng(100 + t);
         std::unique_ptr<RegionData> in_flight;  // odd workers: the begin / finish form, the previous region still on the "device"
+        auto check_sw = [&](const RegionData &rg, const std::vector<SwAlignment> &aln) {
+            if ((int)aln.size() != rg.n_reads) {
+                ++bad;
+                return;
+            }
+            for (int r = 0; r < rg.n_reads; ++r) {
+                if (aln[r].score != (int32_t)(hash_bytes(rg.rb[r].data(), (uint32_t)rg.rb[r].size()) % 100000u)) ++bad;
+                if (aln[r].cigar.size() != 1 || aln[r].cigar[0] != (((uint32_t)rg.rb[r].size() << 4) | 0u)) ++bad;
+            }
+        };
         auto collect = [&](RegionData &rg) {
-            DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(rg.ticket), rg.rs, &rg.arena);
-            bad += rg.mismatches(lik);
+            {
+                DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(rg.ticket), rg.rs, &rg.arena);
+                bad += rg.mismatches(lik);
+            }
+            std::vector<SwAlignment> aln;
+            if (!sw_hip_align_batch_finish(std::move(rg.sw_ticket), aln)) ++bad;
+            check_sw(rg, aln);
         };
         for (int k = 0; k < per_thread; ++k) {
             std::unique_ptr<RegionData> cur(new RegionData(rng));
@@ -155,24 +171,23 @@ int main()
             const int n_reads = rg.n_reads, n_haps = rg.n_haps;
             auto &rb = rg.rb;
             auto &hb = rg.hb;
+            // Smith-Waterman batcher: one request per region
+            std::vector<SwJob> jobs;
+            for (int r = 0; r < n_reads; ++r) jobs.push_back(SwJob{hb[r % n_haps].data(), (int32_t)hb[r % n_haps].size(), rb[r].data(), (int32_t)rb[r].size()});
+            const sw_parameters para{10, -15, -30, -5};
             if (t & 1) {
+                // both seams in two halves: this region's evaluation and realignment are queued, the previous region is collected
                 rg.ticket = call_gpu_pairhmm_begin(rg.hs, rg.rs, 18, PcrIndelModel::NONE);
+                rg.sw_ticket = sw_hip_align_batch_begin(jobs.data(), jobs.size(), para);
                 if (in_flight) collect(*in_flight);
                 in_flight = std::move(cur);
             }
             else {
                 DoubleVector2D lik = call_pairhmm(rg.hs, rg.rs, 18, PcrIndelModel::NONE, &rg.arena);
                 bad += rg.mismatches(lik);
-            }
-            // Smith-Waterman batcher: one request per region
-            std::vector<SwJob> jobs;
-            for (int r = 0; r < n_reads; ++r) jobs.push_back(SwJob{hb[r % n_haps].data(), (int32_t)hb[r % n_haps].size(), rb[r].data(), (int32_t)rb[r].size()});
-            std::vector<SwAlignment> aln;
-            const sw_parameters para{10, -15, -30, -5};
-            if (!sw_hip_align_batch(jobs.data(), jobs.size(), para, aln)) ++bad;
-            for (int r = 0; r < n_reads; ++r) {
-                if (aln[r].score != (int32_t)(hash_bytes(rb[r].data(), (uint32_t)rb[r].size()) % 100000u)) ++bad;
-                if (aln[r].cigar.size() != 1 || aln[r].cigar[0] != (((uint32_t)rb[r].size() << 4) | 0u)) ++bad;
+                std::vector<SwAlignment> aln;
+                if (!sw_hip_align_batch(jobs.data(), jobs.size(), para, aln)) ++bad;
+                check_sw(rg, aln);
             }
         }
         if (in_flight) collect(*in_flight);
@@ -180,6 +195,8 @@ int main()
         if (t & 1) {
             RegionData rg(rng);
             rg.ticket = call_gpu_pairhmm_begin(rg.hs, rg.rs, 18, PcrIndelModel::NONE);
+            const SwJob one{rg.hb[0].data(), (int32_t)rg.hb[0].size(), rg.rb[0].data(), (int32_t)rg.rb[0].size()};
+            rg.sw_ticket = sw_hip_align_batch_begin(&one, 1, sw_parameters{10, -15, -30, -5});
         }
     };
     std::vector<std::thread> th;
@@ -190,7 +207,7 @@ int main()
     sw_hip_batching_stats(&rq, &sw_subs);
     printf("batchers: %llu regions in %llu submissions, %llu alignment requests in %llu submissions, %d mismatches\n",
            (unsigned long long)regions, (unsigned long long)subs, (unsigned long long)rq, (unsigned long long)sw_subs, bad.load());
-    if (bad.load() || regions != (uint64_t)threads * per_thread + threads / 2 || subs >= regions || sw_subs >= rq) return 1;
+    if (bad.load() || regions != (uint64_t)threads * per_thread + threads / 2 || subs >= regions || sw_subs >= rq || rq != (uint64_t)threads * per_thread + threads / 2) return 1;
     fflush(stdout);
     _Exit(0);  // the dispatcher threads are never joined (by design); leave without static teardown
 }

@@ -256,3 +256,46 @@ def test_concurrent_callers_are_batched_and_each_gets_its_own_result():
         o = oracle.sw_align(ref, seq, oracle.SW_PARAMS_ASSEMBLE if asm else oracle.SW_PARAMS_GENOTYPE)
         assert rc == 0 and (sc, mi, mj, off) == (o["score"], o["max_i"], o["max_j"], o["alignment_offset"])
         assert np.array_equal(cig, o["cigar"])
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_align_batch_in_two_halves_keeps_requests_in_flight(depth):
+    # sw_hip_align_batch_begin / _finish (SURVEY 8f next-1's futures, for the second seam): several requests of one caller in
+    # flight at a time give the results of the synchronous call, request by request, empty requests and both parameter sets included
+    import ctypes as C
+    L = C.CDLL(os.path.join(os.path.dirname(swapi.__file__), "lib", "librovaca_sw_host.so"))
+    f = L.rovaca_amd_sw_batches_in_flight
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(57)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for asm in (0, 1):
+        refs, seqs, starts = [], [], [0]
+        for g in range(9):
+            for _ in range(0 if g == 4 else int(rng.integers(1, 30))):  # request 4 is empty
+                ref = acgt[rng.integers(0, 4, int(rng.integers(60, 420)))]
+                n2 = int(rng.integers(15, min(len(ref), 160)))
+                a = int(rng.integers(0, len(ref) - n2 + 1))
+                seq = ref[a:a + n2].copy()
+                seq[rng.random(n2) < 0.04] = ord("G")
+                if rng.random() < 0.3:
+                    k = int(rng.integers(1, n2 - 1))
+                    seq = np.concatenate([seq[:k], acgt[rng.integers(0, 4, 4)], seq[k:]])
+                refs.append(ref)
+                seqs.append(seq)
+            starts.append(len(refs))
+        n = len(refs)
+        rlen, slen = np.array([len(x) for x in refs], np.uint32), np.array([len(x) for x in seqs], np.uint32)
+        roff = np.concatenate([[0], np.cumsum(rlen)[:-1]]).astype(np.uint32)
+        soff = np.concatenate([[0], np.cumsum(slen)[:-1]]).astype(np.uint32)
+        rb, sb = np.ascontiguousarray(np.concatenate(refs)), np.ascontiguousarray(np.concatenate(seqs))
+        cap = (rlen + slen + 8).astype(np.uint32)
+        cat = np.concatenate([[0], np.cumsum(cap)[:-1]]).astype(np.uint32)
+        result, cigars = np.zeros((n, 6), np.int32), np.zeros(int(cap.sum()), np.uint32)
+        st = np.array(starts, np.uint32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert f(p(rb), p(roff), p(rlen), p(sb), p(soff), p(slen), p(st), len(starts) - 1, asm, depth, p(result), p(cigars), p(cat)) == 0
+        for k in range(n):
+            o = oracle.sw_align(refs[k], seqs[k], oracle.SW_PARAMS_ASSEMBLE if asm else oracle.SW_PARAMS_GENOTYPE)
+            assert tuple(int(x) for x in result[k][:4]) == (o["score"], o["max_i"], o["max_j"], o["alignment_offset"]), k
+            assert np.array_equal(cigars[cat[k]:cat[k] + result[k][5]], o["cigar"]), k

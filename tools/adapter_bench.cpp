@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <memory>
 #include <memory_resource>
 #include <random>
@@ -96,9 +97,12 @@ int main(int argc, char **argv)
         HaplotypeVector hs{&arena};
         Region *rg = nullptr;
         PairhmmTicket ticket;
+        // realignment stage (with_sw): decoded reads the jobs point at, and the ticket of the device call
+        std::vector<std::vector<uint8_t>> seqs;
+        SwTicket sw_ticket;
     };
     auto work = [&](int t) {
-        if (depth <= 1) {  // the seam as the reference calls it: one region at a time, synchronously
+        if (depth <= 1) {  // the seams as the reference calls them: one region at a time, synchronously
             for (int k = 0; k < per_thread; ++k) {
                 Region &rg = regions[(t + k) % regions.size()];
                 std::pmr::monotonic_buffer_resource arena;
@@ -111,30 +115,69 @@ int main(int argc, char **argv)
             }
             return;
         }
-        // begin/finish: region k + depth - 1 is handed to the device before region k is collected
-        std::vector<std::unique_ptr<InFlight>> ring(depth);
-        for (int k = 0; k < per_thread + depth - 1; ++k) {
-            std::unique_ptr<InFlight> &slot = ring[k % depth];
-            if (slot) {
-                {
-                    DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(slot->ticket), slot->rs, &slot->arena);
-                    after_pairhmm(*slot->rg, slot->hs, slot->rs, lik);
-                }  // the matrix lives in the slot's arena: gone before the arena is
-                slot.reset();
+        // begin/finish forms: up to `depth` regions wait for their PairHMM and, with sw, up to `depth` for their realignment
+        std::deque<std::unique_ptr<InFlight>> ph_q, sw_q;
+        const sw_parameters genotype{10, -15, -30, -5};  // sw_avx.c:14
+        auto finish_sw = [&](InFlight &f) {
+            std::vector<SwAlignment> aln;
+            if (!sw_hip_align_batch_finish(std::move(f.sw_ticket), aln)) exit(3);
+            sw_elems += aln.empty() ? 0 : aln[0].cigar.size();
+        };
+        auto finish_pairhmm = [&](std::unique_ptr<InFlight> slot) {
+            InFlight &f = *slot;
+            bool realign = false;
+            {
+                DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(f.ticket), f.rs, &f.arena);
+                cells += f.rg->cells;
+                kept += f.rs.size();
+                if (with_sw && !f.rs.empty()) {
+                    f.seqs.resize(f.rs.size());
+                    std::vector<SwJob> jobs(f.rs.size());
+                    for (size_t r = 0; r < f.rs.size(); ++r) {
+                        size_t best = 0;
+                        for (size_t h = 1; h < f.hs.size(); ++h)
+                            if (lik[h][r] > lik[best][r]) best = h;
+                        f.seqs[r].resize(sizeof(Bases) + (size_t)f.rs[r]->seq_length() + 1);
+                        pBases b = reinterpret_cast<pBases>(f.seqs[r].data());
+                        f.rs[r]->decode_base(b);
+                        const pBases hap = f.hs[best]->get_display_string();
+                        jobs[r] = SwJob{hap->data, (int32_t)hap->num, b->data, (int32_t)b->num};
+                        sw_cells += (uint64_t)hap->num * b->num;
+                    }
+                    f.sw_ticket = sw_hip_align_batch_begin(jobs.data(), jobs.size(), genotype);
+                    realign = true;
+                }
+            }  // the matrix lives in the slot's arena: gone before the arena is
+            if (realign) {
+                sw_q.push_back(std::move(slot));
+                if ((int)sw_q.size() >= depth) {
+                    finish_sw(*sw_q.front());
+                    sw_q.pop_front();
+                }
             }
-            if (k < per_thread) {
-                slot.reset(new InFlight());
-                slot->rg = &regions[(t + k) % regions.size()];
-                for (auto &r : slot->rg->reads) slot->rs.push_back(&r);
-                for (auto &h : slot->rg->haps) slot->hs.push_back(&h);
-                slot->ticket = call_gpu_pairhmm_begin(slot->hs, slot->rs, 18, PcrIndelModel::CONSERVATIVE);
+        };
+        for (int k = 0; k < per_thread; ++k) {
+            std::unique_ptr<InFlight> slot(new InFlight());
+            slot->rg = &regions[(t + k) % regions.size()];
+            for (auto &r : slot->rg->reads) slot->rs.push_back(&r);
+            for (auto &h : slot->rg->haps) slot->hs.push_back(&h);
+            slot->ticket = call_gpu_pairhmm_begin(slot->hs, slot->rs, 18, PcrIndelModel::CONSERVATIVE);
+            ph_q.push_back(std::move(slot));
+            if ((int)ph_q.size() >= depth) {
+                std::unique_ptr<InFlight> done = std::move(ph_q.front());
+                ph_q.pop_front();
+                finish_pairhmm(std::move(done));
             }
         }
-        for (auto &slot : ring)
-            if (slot) {
-                DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(slot->ticket), slot->rs, &slot->arena);
-                after_pairhmm(*slot->rg, slot->hs, slot->rs, lik);
-            }
+        while (!ph_q.empty()) {
+            std::unique_ptr<InFlight> done = std::move(ph_q.front());
+            ph_q.pop_front();
+            finish_pairhmm(std::move(done));
+        }
+        while (!sw_q.empty()) {
+            finish_sw(*sw_q.front());
+            sw_q.pop_front();
+        }
     };
     work(0);  // warm up: contexts, tables, kernels
     cells = 0;
