@@ -29,6 +29,7 @@ while time.time() < t_end:
     haps = [acgt[rng.integers(0, 5 if rng.random() < 0.2 else 4, int(rng.integers(1, hmax)))] for _ in range(n_haps)]
     reads = []
     general = rng.random() < 0.3
+    uniform_gop = None if general or rng.random() < 0.5 else int(rng.choice([45, 40, 33, 20]))  # one gap-open in the batch: the shared-product kernel
     for _ in range(n_reads):
         R = int(rng.integers(1, rmax))
         hap = haps[int(rng.integers(0, n_haps))]
@@ -41,6 +42,9 @@ while time.time() < t_end:
         q = rng.integers(2, 60, R).astype(np.uint8)
         if general:
             gi, gd, gc = (rng.integers(5, 50, R).astype(np.uint8) for _ in range(3))
+        elif uniform_gop is not None:
+            gi = gd = np.full(R, uniform_gop, np.uint8)
+            gc = np.full(R, 10, np.uint8)
         else:
             gi = gd = rng.choice(np.array([45, 40, 35], np.uint8), R)
             gc = np.full(R, 10, np.uint8)
