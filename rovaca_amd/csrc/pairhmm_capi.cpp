@@ -1340,13 +1340,29 @@ static bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
     }
     // Chunk sizes rise and fall (1 : 2 : 3 : 3 : 2 : 1): the first chunk's packing and the last chunk's host log10 are the
     // only host work the device cannot hide, so those two chunks are the small ones.
-    const unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(2, n / kChunkTargetPairs + 2));
+    unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(2, n / kChunkTargetPairs + 2));
+    std::vector<unsigned> weight(C);
+    for (unsigned k = 0; k < C; ++k) weight[k] = std::min(k + 1, std::min(C - k, 3u));
+    if (const char *e = getenv("PHMM_CHUNK_WEIGHTS")) {  // tuning aid: relative chunk sizes, e.g. "1,2,3,2,1"
+        std::vector<unsigned> w;
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const unsigned long v = strtoul(q, &end, 10);
+            if (end == q) break;
+            if (v) w.push_back((unsigned)std::min<unsigned long>(v, 1000));
+            q = *end ? end + 1 : end;
+        }
+        if (w.size() >= 2 && w.size() <= 16) {
+            weight = w;
+            C = (unsigned)w.size();
+        }
+    }
     std::vector<uint64_t> cut(C + 1, 0);
     {
         uint64_t wsum = 0, run = 0;
-        for (unsigned k = 0; k < C; ++k) wsum += std::min(k + 1, std::min(C - k, 3u));
+        for (unsigned k = 0; k < C; ++k) wsum += weight[k];
         for (unsigned k = 0; k < C; ++k) {
-            run += std::min(k + 1, std::min(C - k, 3u));
+            run += weight[k];
             cut[k + 1] = cross ? (uint64_t)b->n_reads * run / wsum : n * run / wsum;
         }
     }
