@@ -148,3 +148,38 @@ def test_pairhmm_seam_mirror_against_the_reference_headers():
         nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "rovaca_amd", "lib", "librovaca_pairhmm_host.so")],
                             capture_output=True, text=True, check=True).stdout
         assert symbols[0][0] in nm
+
+
+def test_public_headers_are_plain_c_and_link_from_a_c_program():
+    # the drop-in boundary is a C ABI (extern "C", plain pointers and sizes): both headers must compile as C99 with -pedantic,
+    # and a C program must link against the libraries and reach the version / error entry points (no compute: no device here)
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    lib = os.path.join(ROOT, "rovaca_amd", "lib")
+    src = r'''
+#include <stdio.h>
+#include "pairhmm_hip.h"
+#include "smithwaterman_hip.h"
+int main(void)
+{
+    phmm_batch b;
+    phmm_stats st;
+    swhip_batch sb;
+    (void)b; (void)st; (void)sb;
+    printf("%d %d %d\n", phmm_abi_version(), swhip_abi_version(), (int)sizeof(phmm_batch));
+    return phmm_last_error() == 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "use.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "use")
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), c, "-o", exe,
+                            "-L" + lib, "-lrovaca_pairhmm_hip", "-lrovaca_sw_hip", "-Wl,-rpath," + lib], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.split() == ["4", "1", str(ctypes.sizeof(capi.PhmmBatch))]
