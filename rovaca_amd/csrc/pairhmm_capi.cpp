@@ -207,6 +207,7 @@ static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t m
 constexpr uint32_t kSinglePassMaxHap = 4096;
 constexpr uint32_t kMaxLen = 1u << 20;
 constexpr uint64_t kQueuePerClassMinPairs = 50000;  // batches above this re-run each single-pass class from its own queue
+constexpr uint32_t kXcdLocalMinPairs = 1u << 18;  // single-pass launches from this many pairs on order their workgroups XCD-locally
 constexpr uint32_t kWideMaxPairs = 1536;       // single-pass launches up to this many pairs run one pair per wave
 constexpr uint32_t kRescueMaxTeams = 4096;    // workgroups of the fp64 re-run (they stride over the rescue queue)
 constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
@@ -1042,7 +1043,12 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
                 if (l == 16 || l == 64) lanes = l;
             }
             const int k = lanes == 64 ? (int)((bin.max_read_len + 63) / 64) : bin.rows_per_lane;
+            // big four-pairs-per-wave launches: runs of 64 workgroups (1 024 pairs, a region or so) per XCD, see KernelArgs
+            uint32_t xcd_min = kXcdLocalMinPairs;
+            if (const char *f = getenv("PHMM_XCD_LOCAL_MIN_PAIRS")) xcd_min = (uint32_t)std::max(1, atoi(f));  // tests: small launches too
+            if (lanes == 16 && bin.count >= xcd_min && !getenv("PHMM_NO_XCD_LOCAL_ORDER")) a.xcd_run_log2 = 6;
             HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream, rb->uniform_gop));
+            a.xcd_run_log2 = 0;
         }
         else if (bin.max_read_len <= 64u * phmm::kMaxRowsPerLaneWide && bin.max_hap_len <= kSinglePassMaxHap &&
                  !getenv("PHMM_NO_WIDE_SINGLE_PASS")) {

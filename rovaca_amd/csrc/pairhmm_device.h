@@ -52,6 +52,11 @@ struct KernelArgs
     uint32_t *rescue_count;
     // fp64 re-run: the number of pairs in `order` is read from device memory (no host round trip between the passes)
     const uint32_t *n_pairs_dev;
+    // single-pass kernels, big launches: log2 of the run of consecutive workgroups (in processing order) that one XCD takes, 0 = plain
+    // order.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own L2), and the pairs of a
+    // region -- which share their reads and haplotypes -- sit next to each other in the processing order: with runs of 64 workgroups
+    // (1 024 pairs) per XCD a region's bytes are fetched into one L2 instead of eight.
+    uint32_t xcd_run_log2;
 };
 
 // lanes_per_pair 16: rows_per_lane = ceil(R / 16) in 1..kMaxRowsPerLane; 64: ceil(R / 64) in 1..kMaxRowsPerLaneWide

@@ -167,6 +167,14 @@ struct Rows
 // single region): a quarter of the rows per lane makes the sweep of a pair about twice as short.
 template <int G> constexpr int systolic_block_threads() { return G == 64 ? 64 : kBlockThreads; }
 
+// which workgroup of the processing order this hardware workgroup takes (KernelArgs::xcd_run_log2); wave-uniform scalar work
+__device__ __forceinline__ uint32_t xcd_local_workgroup(uint32_t b, uint32_t run_log2)
+{
+    if (run_log2 == 0) return b;
+    const uint32_t xcd = b & 7u, i = b >> 3;
+    return ((((i >> run_log2) << 3) + xcd) << run_log2) | (i & ((1u << run_log2) - 1u));
+}
+
 template <typename T, int K, bool UG, int G>
 __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHMM_MIN_WAVES(T, K, UG))
     pairhmm_systolic_kernel(KernelArgs a)
@@ -174,7 +182,7 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & (uint32_t)(G - 1);                      // lane inside the pair's G-lane array
     const uint32_t grp_in_block = threadIdx.x / (uint32_t)G;                    // 0..15 (G = 16), 0 (G = 64)
-    const uint32_t gidx = blockIdx.x * (systolic_block_threads<G>() / G) + grp_in_block;
+    const uint32_t gidx = xcd_local_workgroup(blockIdx.x, a.xcd_run_log2) * (systolic_block_threads<G>() / G) + grp_in_block;
     const bool valid = gidx < a.n_pairs;
     const uint32_t pair = a.order[valid ? gidx : 0];
     const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
@@ -389,7 +397,7 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & (uint32_t)(G - 1);                      // lane inside the pair's G-lane array
     const uint32_t grp_in_block = threadIdx.x / (uint32_t)G;                    // 0..15 (G = 16), 0 (G = 64)
-    const uint32_t gidx = blockIdx.x * (systolic_block_threads<G>() / G) + grp_in_block;
+    const uint32_t gidx = xcd_local_workgroup(blockIdx.x, a.xcd_run_log2) * (systolic_block_threads<G>() / G) + grp_in_block;
     const bool valid = gidx < a.n_pairs;
     const uint32_t pair = a.order[valid ? gidx : 0];
     const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
@@ -1567,12 +1575,20 @@ __device__ __forceinline__ void prep_one_read(const uint8_t *__restrict__ read_b
 // ----------------------------------------------------------------------------------------------------
 // launchers (one instantiation per rows-per-lane K)
 // ----------------------------------------------------------------------------------------------------
+// grid of a single-pass launch: with XCD-local ordering it is rounded up to whole rounds of 8 runs (the extra workgroups find no pair)
+static uint32_t systolic_grid(uint32_t blocks, uint32_t xcd_run_log2)
+{
+    if (xcd_run_log2 == 0) return blocks;
+    const uint32_t round = 8u << xcd_run_log2;
+    return (blocks + round - 1) / round * round;
+}
+
 template <typename T, int K, bool UG, int G>
 static hipError_t launch_one(const KernelArgs &a, hipStream_t s)
 {
     constexpr uint32_t threads = systolic_block_threads<G>();
     const uint32_t groups_per_block = threads / G;
-    const uint32_t blocks = (a.n_pairs + groups_per_block - 1) / groups_per_block;
+    const uint32_t blocks = systolic_grid((a.n_pairs + groups_per_block - 1) / groups_per_block, a.xcd_run_log2);
     const size_t shmem = static_cast<size_t>(groups_per_block) * a.lds_words_per_group * sizeof(uint32_t);
     hipLaunchKernelGGL((pairhmm_systolic_kernel<T, K, UG, G>), dim3(blocks), dim3(threads), shmem, s, a);
     return hipGetLastError();
@@ -1583,7 +1599,7 @@ static hipError_t launch_one_ugo(const KernelArgs &a, hipStream_t s)
 {
     constexpr uint32_t threads = systolic_block_threads<G>();
     const uint32_t groups_per_block = threads / G;
-    const uint32_t blocks = (a.n_pairs + groups_per_block - 1) / groups_per_block;
+    const uint32_t blocks = systolic_grid((a.n_pairs + groups_per_block - 1) / groups_per_block, a.xcd_run_log2);
     const size_t shmem = static_cast<size_t>(groups_per_block) * a.lds_words_per_group * sizeof(uint32_t);
     hipLaunchKernelGGL((pairhmm_systolic_ugo_kernel<T, K, G>), dim3(blocks), dim3(threads), shmem, s, a);
     return hipGetLastError();

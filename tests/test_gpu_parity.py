@@ -424,3 +424,23 @@ def test_uniform_gap_open_kernel_is_the_general_one(engine, lanes, monkeypatch):
     b.read_del[:] = 45
     hraw, _, _ = engine.compute(b)
     assert np.array_equal(praw.view(np.uint32), hraw.view(np.uint32))
+
+
+def test_xcd_local_workgroup_order_changes_no_result(engine, monkeypatch):
+    # big single-pass launches hand runs of 64 consecutive workgroups to one XCD (KernelArgs::xcd_run_log2): the grid is rounded up to
+    # whole rounds of 8 runs and every hardware workgroup takes another slice of the processing order.  Forced onto launches of every
+    # size here -- far fewer workgroups than one round, just below / at / above a round, several rounds, mixed lengths -- the sums must be
+    # those of the plain order and of the oracle, and every pair must be written exactly once
+    monkeypatch.setenv("PHMM_FORCE_LANES", "16")
+    for n_regions, reads, haps in ((1, 3, 2), (8, 32, 32), (9, 32, 29), (40, 40, 25)):
+        b = synth.make_batch(seed=300 + n_regions, n_regions=n_regions, reads=reads, haps=haps, read_len=(60, 160), hap_len=(150, 330))
+        monkeypatch.setenv("PHMM_XCD_LOCAL_MIN_PAIRS", "1")
+        raw, l10, _ = engine.compute(b)
+        monkeypatch.delenv("PHMM_XCD_LOCAL_MIN_PAIRS")
+        monkeypatch.setenv("PHMM_NO_XCD_LOCAL_ORDER", "1")
+        raw0, l10_0, _ = engine.compute(b)
+        monkeypatch.delenv("PHMM_NO_XCD_LOCAL_ORDER")
+        assert np.array_equal(raw.view(np.uint32), raw0.view(np.uint32)) and np.array_equal(l10, l10_0, equal_nan=True)
+        k = np.random.default_rng(n_regions).choice(b.n_pairs, min(b.n_pairs, 300), replace=False)
+        want = oracle.batch(b.subset(k))[0]
+        assert np.array_equal(raw[k].view(np.uint32), want.view(np.uint32))
