@@ -33,16 +33,26 @@ def test_host_logic_and_oracles_are_clean_under_asan_ubsan():
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-def test_batchers_are_race_free_under_tsan():
+def test_batchers_are_race_free_under_tsan_and_clean_under_asan():
     # the two cross-region batchers (adapter code as shipped) over stand-in device libraries: ThreadSanitizer watches the
     # hand-offs between 12 workers and the dispatcher threads; every worker checks that it got its own region's numbers
     host = os.path.join(ROOT, "rovaca_amd", "host")
+    srcs = [os.path.join(ROOT, "tests", "sanitize", "batcher_tsan.cpp"), os.path.join(host, "pairhmm_gpu_engine.cpp"),
+            os.path.join(host, "pairhmm_host_logic.cpp"), os.path.join(host, "sw_gpu_engine.cpp")]
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "batcher_tsan")
-        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer",
-               os.path.join(ROOT, "tests", "sanitize", "batcher_tsan.cpp"), os.path.join(host, "pairhmm_gpu_engine.cpp"),
-               os.path.join(host, "pairhmm_host_logic.cpp"), os.path.join(host, "sw_gpu_engine.cpp"), "-o", exe, "-lpthread"]
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", *srcs, "-o", exe, "-lpthread"]
         subprocess.run(cmd, check=True)
         r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
         assert r.returncode == 0, r.stdout + r.stderr
         assert "0 mismatches" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr
+        # the same harness (both seams, synchronous and in two halves, tickets dropped unfinished) under AddressSanitizer + UBSan:
+        # lifetimes of the tickets' buffers against the dispatchers that write into them (leak check off: the dispatcher threads
+        # and their queues are never torn down, by design)
+        exe = os.path.join(d, "batcher_asan")
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", *srcs,
+               "-o", exe, "-lpthread"]
+        subprocess.run(cmd, check=True)
+        r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "0 mismatches" in r.stdout
