@@ -1,0 +1,43 @@
+"""bench.py prints ONE JSON line with the keys the driver reads; checked on the CPU backend here and on the device under -m gpu."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config"}
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # one line, nothing else on stdout
+    return json.loads(lines[0])
+
+
+def test_cpu_backend_line_has_the_contract_keys():
+    d = _run("--backend", "cpu", "--config", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert REQUIRED <= set(d)
+    assert d["metric"] == "PairHMM GCUPS" and d["unit"] == "GCUPS" and d["n_gpus"] == 0 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["value"] > 0 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.gpu
+def test_device_line_has_roofline_and_cpu_baseline():
+    d = _run("--scale", "0.05", "--steps", "3", "--warmup", "1", "--cpu-threads", "4")
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak" and d["data"] == "synthetic"
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-5 and roof["kernel_ms"] > 0
+    # algorithmic bytes: 3R + H + 4 per pair = 754 B at 150 x 300
+    assert roof["algorithmic_bytes"] == 754 * d["config"]["pairs_per_gpu"]
+    base = d["cpu_baseline"]
+    assert base["kind"] in ("reference", "port") and base["cores"] == 4 and base["value"] > 0 and base["host_cores"] >= 1
+    assert base["bit_identical_to_gpu_fp32"] is True and d["max_abs_delta_log10_vs_cpu"] == 0.0
+    assert d["e2e"]["identical_to_resident_path"] is True and d["e2e"]["value"] > 0
+    assert d["pcr_capped_gap_open"]["kernel_gcups"] > 0
