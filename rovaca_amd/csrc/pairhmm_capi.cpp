@@ -1679,8 +1679,10 @@ namespace impl
 {
 
 // run fn(device index) on one thread per device; the first failure's status and text are handed to the calling thread
+// `degraded` (nullable) is set before any un-started body runs on the caller when a helper thread could not be created: bodies
+// that meet at a gate must then stop waiting for each other (they run one after another)
 template <typename F>
-static int on_every_device(phmm_multi *m, F &&fn)
+static int on_every_device(phmm_multi *m, F &&fn, std::atomic<bool> *degraded = nullptr)
 {
     const size_t n = m->ctx.size();
     std::vector<int> rc(n, PHMM_OK);
@@ -1705,6 +1707,7 @@ static int on_every_device(phmm_multi *m, F &&fn)
     }
     catch (...) {
     }
+    if (started < n && degraded) degraded->store(true, std::memory_order_release);
     body(0);
     for (size_t g = started; g < n; ++g) body(g);
     for (auto &t : th) t.join();
@@ -1886,23 +1889,28 @@ int phmm_multi_sweep_timed(phmm_multi *m, phmm_multi_resident *rb, int iters, do
     const size_t n = m->ctx.size();
     // every device thread waits at the gate, sweeps `iters` passes bracketed by HIP events on its own stream and reports its
     // wall time from the common start; the job's time is the slowest device's
+    // (the gate is used only while every device has a thread of its own: when a helper thread could not be started the
+    // remaining bodies run one after another on the caller, `serial` is set first and nobody waits for a body that has not begun;
+    // the common start is then the call's own)
     std::atomic<size_t> arrived{0};
-    std::atomic<bool> go{false};
-    std::chrono::steady_clock::time_point t_start;
+    std::atomic<bool> go{false}, serial{false};
+    const auto t_entry = std::chrono::steady_clock::now();
+    std::atomic<int64_t> start_ns{0};  // offset of the common start from t_entry
     std::vector<double> wall(n, 0.0), dev(n, 0.0), f32(n, 0.0);
     const int rc = on_every_device(m, [&](size_t g) {
         int r = impl::phmm_synchronize(m->ctx[g]);
-        if (arrived.fetch_add(1) + 1 == n) {
-            t_start = std::chrono::steady_clock::now();
+        if (arrived.fetch_add(1) + 1 == n && !serial.load(std::memory_order_acquire)) {
+            start_ns.store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count());
             go.store(true, std::memory_order_release);
         }
-        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        while (!go.load(std::memory_order_acquire) && !serial.load(std::memory_order_acquire)) std::this_thread::yield();
         if (r != PHMM_OK) return r;
         r = impl::phmm_sweep_timed(m->ctx[g], rb->part[g], iters, &dev[g], &f32[g]);
         if (r == PHMM_OK) r = impl::phmm_synchronize(m->ctx[g]);
+        const auto t_start = t_entry + std::chrono::nanoseconds(start_ns.load());
         wall[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
         return r;
-    });
+    }, &serial);
     if (rc != PHMM_OK) return rc;
     double w = 0.0;
     for (size_t g = 0; g < n; ++g) w = std::max(w, wall[g]);

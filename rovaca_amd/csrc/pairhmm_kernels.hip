@@ -1025,7 +1025,8 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
     uint32_t *pl = lds + grp * plane_words;
     T *ring = reinterpret_cast<T *>(lds + kGroups * plane_words) + (static_cast<size_t>(wave) * kGroups + grp) * 3u * kRing;
     // progress records of the team's waves: [round parity][wave][stripe + 1, supersteps done, first carry block with output, last
-    // carry block with output (once the stripe is finished), superstep the sweep began at, 3 spare words]
+    // carry block with output (once the stripe is finished), superstep the sweep began at, "a wait timed out somewhere up the
+    // chain" flag, 2 spare words]
     uint32_t *team_rec = reinterpret_cast<uint32_t *>(reinterpret_cast<T *>(lds + kGroups * plane_words) + static_cast<size_t>(WP) * kGroups * 3u * kRing);
     // carry rows: one slab per (team, wave), laid out [column][group][M, X, Y] so that the slab base is wave-uniform (an
     // SGPR pair) and lane 15 writes its three values with one store; stripe v reads the slab of the wave that ran v - 1
@@ -1439,11 +1440,16 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 // the carry of a stripe above that may have begun in the middle of the row: the blocks before that point were
                 // never written (they are zero).
                 carry_first_blk = v > 0 ? ld(prec + 4) : 0u;
+                // a wave whose bounded wait expired goes on with unsynchronised carry data: the poison travels down the chain of
+                // stripes through word 5 of the records (sticky per wave, inherited from the stripe above at both ends of a
+                // stripe), so that whichever wave runs the last stripe writes NaN
+                if (v > 0 && ld(prec + 5) != 0u) stuck = true;
                 if (lane == 0) {
                     st(mrec + 4, c_first);
                     st(mrec + 1, c_first);
                     st(mrec + 2, kUnknown);
                     st(mrec + 3, kUnknown);
+                    st(mrec + 5, stuck ? 1u : 0u);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     st(mrec, v + 1);
                 }
@@ -1475,6 +1481,8 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     if (lane == 0) st(mrec + 1, c + 1u);
                     if (skipped && !whole_row && prod_done && c > in_last + 2u) break;
                 }
+                if (v > 0 && ld(prec + 5) != 0u) stuck = true;  // (the stripe above is finished by now: its flag is final)
+                if (lane == 0 && stuck) st(mrec + 5, 1u);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 // The last non-skipped superstep l leaves the last lane at column 32 l + 32 - (G - 1): block l (G = 16) or l - 1
                 // (G = 64); that block is complete once superstep l + 1 has run -- it has, the loop leaves only after a skipped

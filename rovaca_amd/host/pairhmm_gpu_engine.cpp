@@ -344,7 +344,16 @@ struct PairhmmTicket::State
 };
 PairhmmTicket::PairhmmTicket() = default;
 PairhmmTicket::PairhmmTicket(PairhmmTicket &&) noexcept = default;
-PairhmmTicket &PairhmmTicket::operator=(PairhmmTicket &&) noexcept = default;
+PairhmmTicket &PairhmmTicket::operator=(PairhmmTicket &&o) noexcept
+{
+    // assigning over a ticket that is still in flight (a look-ahead loop that skipped finish for the previous region): the
+    // dispatcher reads its tables and writes its result buffer until the job is done, so wait first -- as the destructor does
+    if (this != &o) {
+        if (st_ && st_->batcher) st_->batcher->wait(st_->job);
+        st_ = std::move(o.st_);
+    }
+    return *this;
+}
 PairhmmTicket::~PairhmmTicket()
 {
     // a ticket dropped without finish: the dispatcher may still be writing into it

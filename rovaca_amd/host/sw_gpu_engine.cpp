@@ -247,7 +247,16 @@ struct SwTicket::State
 };
 SwTicket::SwTicket() = default;
 SwTicket::SwTicket(SwTicket &&) noexcept = default;
-SwTicket &SwTicket::operator=(SwTicket &&) noexcept = default;
+SwTicket &SwTicket::operator=(SwTicket &&o) noexcept
+{
+    // assigning over a ticket whose request is still queued or on the device: its State (job records, result slots) must
+    // outlive the dispatcher's writes, exactly as in the destructor
+    if (this != &o) {
+        if (st_ && st_->batcher) st_->batcher->wait(st_->rq);
+        st_ = std::move(o.st_);
+    }
+    return *this;
+}
 SwTicket::~SwTicket()
 {
     if (st_ && st_->batcher) st_->batcher->wait(st_->rq);  // dropped without finish: the dispatcher may still be writing into it

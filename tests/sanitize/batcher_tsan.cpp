@@ -198,6 +198,21 @@ int main()
             const SwJob one{rg.hb[0].data(), (int32_t)rg.hb[0].size(), rg.rb[0].data(), (int32_t)rg.rb[0].size()};
             rg.sw_ticket = sw_hip_align_batch_begin(&one, 1, sw_parameters{10, -15, -30, -5});
         }
+        // a ticket ASSIGNED OVER while its region is still in flight (a look-ahead loop that skipped finish): the old State
+        // must not be freed under the dispatcher (move-assignment waits first, like the destructor)
+        if (t & 1) {
+            RegionData a(rng), b(rng);
+            PairhmmTicket tk = call_gpu_pairhmm_begin(a.hs, a.rs, 18, PcrIndelModel::NONE);
+            tk = call_gpu_pairhmm_begin(b.hs, b.rs, 18, PcrIndelModel::NONE);  // a's evaluation is still queued / on the device
+            const SwJob ja{a.hb[0].data(), (int32_t)a.hb[0].size(), a.rb[0].data(), (int32_t)a.rb[0].size()};
+            const SwJob jb{b.hb[0].data(), (int32_t)b.hb[0].size(), b.rb[0].data(), (int32_t)b.rb[0].size()};
+            SwTicket st = sw_hip_align_batch_begin(&ja, 1, sw_parameters{10, -15, -30, -5});
+            st = sw_hip_align_batch_begin(&jb, 1, sw_parameters{10, -15, -30, -5});
+            DoubleVector2D lik = call_gpu_pairhmm_finish(std::move(tk), b.rs, &b.arena);
+            bad += b.mismatches(lik);
+            std::vector<SwAlignment> aln;
+            if (!sw_hip_align_batch_finish(std::move(st), aln) || aln.size() != 1) ++bad;
+        }
     };
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
@@ -207,7 +222,7 @@ int main()
     sw_hip_batching_stats(&rq, &sw_subs);
     printf("batchers: %llu regions in %llu submissions, %llu alignment requests in %llu submissions, %d mismatches\n",
            (unsigned long long)regions, (unsigned long long)subs, (unsigned long long)rq, (unsigned long long)sw_subs, bad.load());
-    if (bad.load() || regions != (uint64_t)threads * per_thread + threads / 2 || subs >= regions || sw_subs >= rq || rq != (uint64_t)threads * per_thread + threads / 2) return 1;
+    if (bad.load() || regions != (uint64_t)threads * per_thread + 3 * (threads / 2) || subs >= regions || sw_subs >= rq || rq != (uint64_t)threads * per_thread + 3 * (threads / 2)) return 1;
     fflush(stdout);
     _Exit(0);  // the dispatcher threads are never joined (by design); leave without static teardown
 }
