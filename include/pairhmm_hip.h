@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PHMM_ABI_VERSION 4
+#define PHMM_ABI_VERSION 5
 
 /* status codes (0 = ok).  Nothing is thrown across this boundary. */
 enum {
@@ -128,6 +128,71 @@ int phmm_download(phmm_context *ctx, phmm_resident *rb, float *out_raw_f32, doub
 int phmm_download_read_table(phmm_context *ctx, phmm_resident *rb, uint8_t *qual, uint8_t *ins, uint8_t *del, uint8_t *gcp);
 int phmm_synchronize(phmm_context *ctx);
 void phmm_release(phmm_context *ctx, phmm_resident *rb);
+
+/* ---- region-descriptor batches (ABI 5) ----
+ * What the reference's call site hands the seam is not a pair list but REGIONS: all reads of an active region against all its
+ * haplotypes (haplotypecaller_engine.cpp:250 -> pairhmm_internal.cpp:657-669 loops haplotypes inside reads).  A region is
+ * described by four numbers; the engine bins per read (O(reads) host work) and spells the cross products out on the device.
+ * Pair ids count region by region, [read][hap] inside one: region g's results start at sum_{g' < g} n_reads * n_haps.
+ * Regions list their reads in ascending, non-overlapping runs of the read table; haplotypes may be shared between regions. */
+typedef struct phmm_region {
+    uint32_t read_first, n_reads; /* reads [read_first, read_first + n_reads) of the read table */
+    uint32_t hap_first, n_haps;   /* haplotypes [hap_first, hap_first + n_haps) of the haplotype table */
+} phmm_region;
+/* one-shot, host buffers in and out: `tables` is a phmm_batch whose pair_read / pair_hap / n_pairs are ignored */
+int phmm_compute_regions(phmm_context *ctx, const phmm_batch *tables, const phmm_region *regions, uint32_t n_regions,
+                         float *out_raw_f32, double *out_log10, phmm_stats *stats);
+
+/* ---- pinned staging for region batches: the caller writes its tables where the device reads them ----
+ * The cross-region batcher of the drop-in adapter (rovaca_amd/host/pairhmm_gpu_engine.cpp) merges the regions of many worker
+ * threads into one submission.  With host buffers in and out that costs four copies of every byte (worker -> ticket ->
+ * dispatcher -> pinned stage -> HBM) and a pair list spelled out on the host.  A phmm_stage is a block of pinned host memory
+ * owned by the engine and laid out as the device wants it: workers write their reads' RAW base qualities
+ * (ReadRecord::qual()), bases and mapping qualities and their haplotypes straight into it at ranges the caller hands out (any
+ * number of threads, disjoint ranges); one submission is ONE host-to-device copy of the used part of the stage and ONE set-up
+ * launch -- quality modification and PCR indel model (pairhmm_internal.cpp:413-448, :65-159), haplotype bit planes and the
+ * pair list happen there -- followed by the sweep and the fp64 re-run; the kernels write the sums into the stage's pinned
+ * result arrays, where every worker converts its own region (phmm_stage_log10).  No CPU fallback: on a CPU context (phmm_create_cpu) the same calls compute on the host. */
+typedef struct phmm_stage phmm_stage;
+typedef struct phmm_stage_caps {
+    uint32_t max_regions, max_reads, max_haps;
+    uint32_t max_bytes; /* the byte arena: read bases + read qualities + haplotype bases of one submission, gaps included */
+    uint32_t max_pairs;
+} phmm_stage_caps;
+typedef struct phmm_stage_view { /* pinned host memory, valid until phmm_stage_destroy; written by the caller between submissions */
+    uint8_t *bytes;                /* [max_bytes] ONE arena for all sequence bytes, so that a submission is one contiguous copy */
+    uint32_t *read_off;            /* [max_reads] read k's bases are bytes[read_off[k] .. +read_len[k]) */
+    uint32_t *read_qual_off;       /* [max_reads] ... its RAW base qualities bytes[read_qual_off[k] .. +read_len[k]) */
+    uint32_t *read_len;            /* [max_reads] */
+    uint8_t *read_mapq;            /* [max_reads] */
+    uint32_t *hap_off, *hap_len;   /* [max_haps] haplotype h is bytes[hap_off[h] .. +hap_len[h]) */
+    phmm_region *regions;          /* [max_regions] */
+} phmm_stage_view;
+typedef struct phmm_stage_params { /* the constants of phmm_read_prep (no per-read array: the mapping qualities are in the stage) */
+    int32_t min_quality_threshold, pcr_model;
+    uint8_t gap_open, gap_cont;
+} phmm_stage_params;
+int phmm_stage_create(phmm_context *ctx, const phmm_stage_caps *caps, phmm_stage **out);
+void phmm_stage_destroy(phmm_context *ctx, phmm_stage *st);
+int phmm_stage_get_view(const phmm_stage *st, phmm_stage_view *view, phmm_stage_caps *caps /* nullable */);
+/* asynchronous: validates and bins the first n_regions / n_reads / n_haps entries of the stage and enqueues set-up, sweep and
+ * fp64 re-run on the context's stream.  The stage must not be written until phmm_stage_wait has returned. */
+int phmm_stage_submit(phmm_context *ctx, phmm_stage *st, uint32_t n_regions, uint32_t n_reads, uint32_t n_haps,
+                      const phmm_stage_params *params);
+int phmm_stage_wait(phmm_context *ctx, phmm_stage *st, phmm_stats *stats /* nullable; n_rescued is not counted here */);
+/* region g's first pair id in the last submission (the prefix sum above); n_regions gives the total */
+uint64_t phmm_stage_pair_first(const phmm_stage *st, uint32_t region);
+/* out[i] = log10 likelihood of pair first_pair + i (the conversion of phmm_compute, glibc log10f / log10); any thread, after
+ * phmm_stage_wait; *n_rescued (nullable) = how many of them took the fp64 value */
+int phmm_stage_log10(const phmm_stage *st, uint64_t first_pair, uint64_t n, double *out, float *out_raw_f32 /* nullable */,
+                     uint64_t *n_rescued);
+
+/* the binning alone (host only, no device; tests): launches in processing order.  bin_rows[i] = rows per lane of launch i (0 =
+ * striped kernel), bin_first / bin_count = its range of `order` (nullable arrays of capacity max_bins); returns the number of
+ * launches, or a negative status */
+int phmm_plan_bins(const phmm_batch *batch, uint32_t *order, int32_t *bin_rows, uint32_t *bin_first, uint32_t *bin_count, int max_bins);
+int phmm_plan_region_bins(const phmm_batch *tables, const phmm_region *regions, uint32_t n_regions, uint32_t *slot_first,
+                          uint32_t *pair_first, int32_t *bin_rows, uint32_t *bin_first, uint32_t *bin_count, int max_bins);
 
 /* ---- several devices behind one handle ("create(device_ids[], n)"; 8e: plain split, no collective) ----
  * The reference's call site hands one region at a time to the seam from up to 128 workers (haplotypecaller_engine.cpp:119);

@@ -156,6 +156,26 @@ def batch(b, n_threads=1, want_raw=True):
     return raw, l10, resc.astype(bool)
 
 
+def prepare_batch(b, mapq, min_q=18, pcr_model=3, gap_open=45, gap_cont=10):
+    """The read table of a batch with RAW qualities as the reference's decompression_data leaves it (pairhmm_internal.cpp:413-448):
+    phmm_oracle_modify_quals (H3) and phmm_oracle_apply_pcr_error_model (H4) per read, deletion gap-opens aliasing the insertion
+    ones, gap continuation 10.  Returns a new Batch (the pair list and the haplotypes are shared)."""
+    from rovaca_amd.batch import Batch
+    L = lib()
+    qual = b.read_qual.copy()
+    gop = np.full(b.read_bases.shape[0], gap_open, np.uint8)
+    for r in range(b.n_reads):
+        o, n = int(b.read_off[r]), int(b.read_len[r])
+        q = np.ascontiguousarray(qual[o:o + n])
+        L.phmm_oracle_modify_quals(q, n, int(mapq[r]), int(min_q))
+        qual[o:o + n] = q
+        g = np.ascontiguousarray(gop[o:o + n])
+        L.phmm_oracle_apply_pcr_error_model(np.ascontiguousarray(b.read_bases[o:o + n]), g, n, int(pcr_model))
+        gop[o:o + n] = g
+    return Batch(b.read_bases, qual, gop, gop.copy(), np.full_like(gop, gap_cont), b.read_off, b.read_len, b.hap_bases, b.hap_off,
+                 b.hap_len, b.pair_read, b.pair_hap, region_read=b.region_read, region_hap=b.region_hap, region_pair=b.region_pair)
+
+
 def ref_pairs_avx512_s(b, n_threads=1):
     """Reference per-pair AVX-512 fp32 kernel over a flat batch.  Returns (raw_f32, seconds)."""
     R = ref()

@@ -20,7 +20,9 @@ EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy
            "phmm_get_tables", "phmm_download_read_table",
            "phmm_create_multi", "phmm_destroy_multi", "phmm_multi_device_count", "phmm_multi_device_id", "phmm_multi_compute",
            "phmm_multi_upload", "phmm_multi_sweep", "phmm_multi_synchronize", "phmm_multi_sweep_timed", "phmm_multi_download",
-           "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize", "phmm_create_cpu", "phmm_backend_name", "phmm_plan_slices")
+           "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize", "phmm_create_cpu", "phmm_backend_name", "phmm_plan_slices",
+           "phmm_compute_regions", "phmm_stage_create", "phmm_stage_destroy", "phmm_stage_get_view", "phmm_stage_submit", "phmm_stage_wait",
+           "phmm_stage_pair_first", "phmm_stage_log10", "phmm_plan_bins", "phmm_plan_region_bins")
 
 
 class PhmmBatch(C.Structure):
@@ -39,6 +41,24 @@ class PhmmReadPrep(C.Structure):
 class PhmmStats(C.Structure):
     _fields_ = [("cells", C.c_uint64), ("n_rescued", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
                 ("n_launches", C.c_uint32), ("max_rows_per_lane", C.c_uint32)]
+
+
+class PhmmRegion(C.Structure):
+    _fields_ = [("read_first", C.c_uint32), ("n_reads", C.c_uint32), ("hap_first", C.c_uint32), ("n_haps", C.c_uint32)]
+
+
+class PhmmStageCaps(C.Structure):
+    _fields_ = [("max_regions", C.c_uint32), ("max_reads", C.c_uint32), ("max_haps", C.c_uint32), ("max_bytes", C.c_uint32),
+                ("max_pairs", C.c_uint32)]
+
+
+class PhmmStageView(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("read_off", C.c_void_p), ("read_qual_off", C.c_void_p), ("read_len", C.c_void_p),
+                ("read_mapq", C.c_void_p), ("hap_off", C.c_void_p), ("hap_len", C.c_void_p), ("regions", C.c_void_p)]
+
+
+class PhmmStageParams(C.Structure):
+    _fields_ = [("min_quality_threshold", C.c_int32), ("pcr_model", C.c_int32), ("gap_open", C.c_uint8), ("gap_cont", C.c_uint8)]
 
 
 class PhmmError(RuntimeError):
@@ -117,6 +137,27 @@ def lib():
     L.phmm_create_cpu.restype = C.c_int
     L.phmm_backend_name.argtypes = [C.c_void_p]
     L.phmm_backend_name.restype = C.c_char_p
+    L.phmm_compute_regions.argtypes = [C.c_void_p, C.POINTER(PhmmBatch), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(PhmmStats)]
+    L.phmm_compute_regions.restype = C.c_int
+    L.phmm_stage_create.argtypes = [C.c_void_p, C.POINTER(PhmmStageCaps), C.POINTER(C.c_void_p)]
+    L.phmm_stage_create.restype = C.c_int
+    L.phmm_stage_destroy.argtypes = [C.c_void_p, C.c_void_p]
+    L.phmm_stage_destroy.restype = None
+    L.phmm_stage_get_view.argtypes = [C.c_void_p, C.POINTER(PhmmStageView), C.POINTER(PhmmStageCaps)]
+    L.phmm_stage_get_view.restype = C.c_int
+    L.phmm_stage_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PhmmStageParams)]
+    L.phmm_stage_submit.restype = C.c_int
+    L.phmm_stage_wait.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PhmmStats)]
+    L.phmm_stage_wait.restype = C.c_int
+    L.phmm_stage_pair_first.argtypes = [C.c_void_p, C.c_uint32]
+    L.phmm_stage_pair_first.restype = C.c_uint64
+    L.phmm_stage_log10.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.phmm_stage_log10.restype = C.c_int
+    L.phmm_plan_bins.argtypes = [C.POINTER(PhmmBatch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.phmm_plan_bins.restype = C.c_int
+    L.phmm_plan_region_bins.argtypes = [C.POINTER(PhmmBatch), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int]
+    L.phmm_plan_region_bins.restype = C.c_int
     _LIB = L
     return L
 
@@ -148,6 +189,108 @@ def _c_batch(b, cross=False, prep=None):
     cb.pair_read = None if cross else _ptr(b.pair_read)
     cb.pair_hap = None if cross else _ptr(b.pair_hap)
     return cb
+
+
+def regions_of(batch):
+    """The batch's region structure (Batch.region_read / region_hap) as an array of phmm_region; its pair list must be the
+    regions' cross products in order (the synthetic generator's batches are)."""
+    assert batch.region_read is not None, "this batch carries no region structure"
+    n = len(batch.region_read) - 1
+    reg = np.zeros((n, 4), np.uint32)
+    reg[:, 0] = batch.region_read[:-1]
+    reg[:, 1] = np.diff(batch.region_read.astype(np.int64))
+    reg[:, 2] = batch.region_hap[:-1]
+    reg[:, 3] = np.diff(batch.region_hap.astype(np.int64))
+    return np.ascontiguousarray(reg)
+
+
+def plan_bins(batch, cross=False):
+    """The launch plan of a pair-list batch (host only): (order, [(rows_per_lane, first, count), ...])."""
+    cb = _c_batch(batch, cross)
+    n = batch.n_reads * batch.n_haps if cross else batch.n_pairs
+    order = np.zeros(n, np.uint32)
+    rows, first, count = np.zeros(64, np.int32), np.zeros(64, np.uint32), np.zeros(64, np.uint32)
+    nb = lib().phmm_plan_bins(C.byref(cb), _ptr(order), _ptr(rows), _ptr(first), _ptr(count), 64)
+    if nb < 0:
+        raise PhmmError(f"phmm_plan_bins: status {-nb}: {lib().phmm_last_error().decode()}")
+    return order, [(int(rows[i]), int(first[i]), int(count[i])) for i in range(nb)]
+
+
+def plan_region_bins(batch, regions):
+    """The launch plan of a region batch (host only): (slot_first per read, pair_first per region, launches)."""
+    cb = _c_batch(batch)
+    regions = np.ascontiguousarray(regions, np.uint32).reshape(-1, 4)
+    slot = np.zeros(batch.n_reads, np.uint32)
+    pf = np.zeros(len(regions) + 1, np.uint32)
+    rows, first, count = np.zeros(64, np.int32), np.zeros(64, np.uint32), np.zeros(64, np.uint32)
+    nb = lib().phmm_plan_region_bins(C.byref(cb), _ptr(regions), len(regions), _ptr(slot), _ptr(pf), _ptr(rows), _ptr(first), _ptr(count), 64)
+    if nb < 0:
+        raise PhmmError(f"phmm_plan_region_bins: status {-nb}: {lib().phmm_last_error().decode()}")
+    return slot, pf[:-1], [(int(rows[i]), int(first[i]), int(count[i])) for i in range(nb)]
+
+
+class Stage:
+    """Pinned staging for region batches (phmm_stage_*): numpy views of the engine's pinned tables, written in place."""
+
+    def __init__(self, engine, max_regions, max_reads, max_haps, max_bytes, max_pairs):
+        self.engine = engine
+        caps = PhmmStageCaps(max_regions, max_reads, max_haps, max_bytes, max_pairs)
+        h = C.c_void_p()
+        _check(lib().phmm_stage_create(engine.handle, C.byref(caps), C.byref(h)), "phmm_stage_create")
+        self.handle = h
+        v = PhmmStageView()
+        _check(lib().phmm_stage_get_view(h, C.byref(v), None), "phmm_stage_get_view")
+
+        def arr(ptr, ctype, n):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
+        self.bytes = arr(v.bytes, C.c_uint8, max_bytes)
+        self.read_off, self.read_qual_off = arr(v.read_off, C.c_uint32, max_reads), arr(v.read_qual_off, C.c_uint32, max_reads)
+        self.read_len, self.read_mapq = arr(v.read_len, C.c_uint32, max_reads), arr(v.read_mapq, C.c_uint8, max_reads)
+        self.hap_off, self.hap_len = arr(v.hap_off, C.c_uint32, max_haps), arr(v.hap_len, C.c_uint32, max_haps)
+        self.regions = arr(v.regions, C.c_uint32, 4 * max_regions).reshape(max_regions, 4)
+        self.n_pairs = 0
+
+    def fill(self, batch, regions, mapq):
+        """Copy a batch's tables into the stage's arena as [bases][qualities][haplotypes] (tests; the adapter's workers write
+        their regions in place instead, read by read)."""
+        regions = np.asarray(regions, np.uint32).reshape(-1, 4)
+        rb, hb = batch.read_bases.shape[0], batch.hap_bases.shape[0]
+        self.bytes[:rb], self.bytes[rb:2 * rb], self.bytes[2 * rb:2 * rb + hb] = batch.read_bases, batch.read_qual, batch.hap_bases
+        nr, nh = batch.n_reads, batch.n_haps
+        self.read_off[:nr], self.read_qual_off[:nr], self.read_len[:nr] = batch.read_off, batch.read_off + np.uint32(rb), batch.read_len
+        self.read_mapq[:nr] = mapq
+        self.hap_off[:nh], self.hap_len[:nh] = batch.hap_off + np.uint32(2 * rb), batch.hap_len
+        self.regions[:len(regions)] = regions
+        self.n_pairs = int((regions[:, 1].astype(np.int64) * regions[:, 3]).sum())
+        return len(regions), nr, nh
+
+    def submit(self, n_regions, n_reads, n_haps, min_q=18, pcr_model=3, gap_open=45, gap_cont=10):
+        prm = PhmmStageParams(int(min_q), int(pcr_model), int(gap_open), int(gap_cont))
+        _check(lib().phmm_stage_submit(self.engine.handle, self.handle, n_regions, n_reads, n_haps, C.byref(prm)), "phmm_stage_submit")
+
+    def wait(self):
+        st = PhmmStats()
+        _check(lib().phmm_stage_wait(self.engine.handle, self.handle, C.byref(st)), "phmm_stage_wait")
+        return st
+
+    def pair_first(self, region):
+        return int(lib().phmm_stage_pair_first(self.handle, region))
+
+    def log10(self, first, n):
+        out, raw, resc = np.zeros(n, np.float64), np.zeros(n, np.float32), C.c_uint64()
+        _check(lib().phmm_stage_log10(self.handle, first, n, _ptr(out), _ptr(raw), C.byref(resc)), "phmm_stage_log10")
+        return raw, out, int(resc.value)
+
+    def close(self):
+        if self.handle:
+            lib().phmm_stage_destroy(self.engine.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def tables():
@@ -221,6 +364,16 @@ class Engine:
             l10 = np.zeros(n, np.float64)
         st = PhmmStats()
         _check(lib().phmm_compute(self.handle, C.byref(cb), _ptr(raw), _ptr(l10), C.byref(st)), "phmm_compute")
+        return raw, l10, st
+
+    def compute_regions(self, batch, regions, prep=None):
+        """Region-descriptor form of compute (phmm_compute_regions): pair ids count region by region, [read][hap] inside."""
+        cb = _c_batch(batch, True, prep)
+        regions = np.ascontiguousarray(regions, np.uint32).reshape(-1, 4)
+        n = int((regions[:, 1].astype(np.int64) * regions[:, 3]).sum())
+        raw, l10, st = np.zeros(n, np.float32), np.zeros(n, np.float64), PhmmStats()
+        _check(lib().phmm_compute_regions(self.handle, C.byref(cb), _ptr(regions), len(regions), _ptr(raw), _ptr(l10), C.byref(st)),
+               "phmm_compute_regions")
         return raw, l10, st
 
     def upload(self, batch, cross=False, prep=None):

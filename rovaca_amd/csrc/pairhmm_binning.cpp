@@ -1,0 +1,269 @@
+// pairhmm_binning.cpp -- see pairhmm_binning.h.  Host code only: no HIP runtime call in this file.
+#include "pairhmm_binning.h"
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdlib>
+
+namespace phmm_detail
+{
+int fail(int code, const char *fmt, ...);  // pairhmm_capi.cpp: sets the calling thread's phmm_last_error text
+}
+using phmm_detail::fail;
+
+extern char **environ;
+namespace phmm_detail
+{
+thread_local int t_hooks = -1;
+bool any_phmm_variable()
+{
+    for (char **e = environ; e && *e; ++e)
+        if ((*e)[0] == 'P' && (*e)[1] == 'H' && (*e)[2] == 'M' && (*e)[3] == 'M' && (*e)[4] == '_') return true;
+    return false;
+}
+}  // namespace phmm_detail
+const char *phmm_hook(const char *name) { return phmm_detail::t_hooks == 0 ? nullptr : getenv(name); }
+
+bool queue_per_class_for(uint64_t n_pairs) { return n_pairs > kQueuePerClassMinPairs || phmm_hook("PHMM_FORCE_QUEUE_PER_CLASS") != nullptr; }
+
+namespace phmm_detail
+{
+
+int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_bias, uint32_t hap_bias, uint32_t *pr, uint32_t *ph,
+              uint32_t *order, BinScratch &scratch, std::vector<Bin> &bins, uint64_t *cells_out)
+{
+    const bool queue_per_class = queue_per_class_for(n_pairs);
+    uint32_t max_hap = 0;
+    for (uint32_t h = 0; h < b->n_haps; ++h) max_hap = std::max(max_hap, b->hap_len[h]);
+    uint32_t min_hap = max_hap;
+    for (uint32_t h = 0; h < b->n_haps; ++h) min_hap = std::min(min_hap, b->hap_len[h]);
+    const uint32_t hrange = b->n_haps ? max_hap - min_hap + 1 : 1;
+    uint32_t rank[kClasses], n_used = 0, class_rmax[kClasses];
+    {
+        bool used[kClasses] = {false};
+        const bool long_hap = max_hap > kSinglePassMaxHap;
+        for (uint32_t r = 0; r < b->n_reads; ++r) {
+            used[class_of(b->read_len[r], 1)] = true;
+            if (long_hap) used[class_of(b->read_len[r], max_hap)] = true;
+        }
+        for (uint32_t k = 0; k < kClasses; ++k) {
+            rank[k] = n_used;
+            class_rmax[k] = 0;
+            if (used[k]) ++n_used;
+        }
+    }
+    uint64_t cells = 0;
+    const uint64_t table = (uint64_t)n_used * hrange;
+    if (table <= std::max<uint64_t>(4 * n_pairs, 1u << 16)) {
+        std::vector<uint32_t> &hist = scratch.hist, &slot = scratch.slot;
+        hist.assign(table + 1, 0);
+        slot.resize(n_pairs);
+        const unsigned T = (n_pairs >= kParallelMinPairs && table <= (1u << 16)) ? host_threads() : 1u;
+        std::vector<std::vector<uint32_t>> th_hist(T > 1 ? T : 0);
+        std::vector<uint64_t> th_cells(T, 0);
+        std::vector<uint32_t> th_rmax((size_t)T * kClasses, 0);
+        std::atomic<uint64_t> bad_pair{UINT64_MAX};
+        auto count_range = [&](uint64_t lo, uint64_t hi, unsigned t) {
+            uint32_t *h_t = T > 1 ? th_hist[t].data() : hist.data() + 1;  // one thread counts straight into hist[at + 1]
+            uint32_t *rmax_t = th_rmax.data() + (size_t)t * kClasses;
+            uint64_t cells_t = 0;
+            for (uint64_t p = lo; p < hi; ++p) {
+                uint32_t r, h;
+                if (cross) {
+                    r = (uint32_t)(p / b->n_haps);
+                    h = (uint32_t)(p % b->n_haps);
+                }
+                else {
+                    r = b->pair_read[p] - read_bias;  // (an index below the bias wraps and fails the range check)
+                    h = b->pair_hap[p] - hap_bias;
+                    if (r >= b->n_reads || h >= b->n_haps) {
+                        uint64_t expect = UINT64_MAX;
+                        bad_pair.compare_exchange_strong(expect, p);
+                        return;
+                    }
+                }
+                const uint32_t R = b->read_len[r], H = b->hap_len[h];
+                const uint32_t k = class_of(R, H);
+                rmax_t[k] = std::max(rmax_t[k], R);
+                const uint32_t at = rank[k] * hrange + (max_hap - H);
+                pr[p] = r;
+                ph[p] = h;
+                slot[p] = at;
+                ++h_t[at];
+                cells_t += (uint64_t)R * H;
+            }
+            th_cells[t] = cells_t;
+        };
+        if (T > 1) {
+            for (auto &v : th_hist) v.assign(table, 0);
+            parallel_ranges(n_pairs, T, count_range);
+            for (unsigned t = 0; t < T; ++t)
+                for (uint64_t i = 0; i < table; ++i) hist[i + 1] += th_hist[t][i];
+        }
+        else {
+            count_range(0, n_pairs, 0);
+        }
+        if (bad_pair.load() != UINT64_MAX)
+            return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)bad_pair.load());
+        for (unsigned t = 0; t < T; ++t) {
+            cells += th_cells[t];
+            for (uint32_t k = 0; k < kClasses; ++k) class_rmax[k] = std::max(class_rmax[k], th_rmax[(size_t)t * kClasses + k]);
+        }
+        for (uint64_t i = 0; i < table; ++i) hist[i + 1] += hist[i];  // hist[i] = first position of slot i
+        // bins: classes 1..16 one each, the striped classes in four size ranges
+        for (uint32_t k = 1; k < kClasses;) {
+            uint32_t k_end = k + 1;
+            while (k_end < kClasses && bin_id_of_class(k_end) == bin_id_of_class(k)) ++k_end;
+            const uint32_t lo = rank[k], hi = k_end < kClasses ? rank[k_end] : n_used;
+            const uint32_t first = hist[(uint64_t)lo * hrange], end = hist[(uint64_t)hi * hrange];
+            if (end > first) {
+                uint32_t hmax = 0, rmax = 0;
+                for (uint32_t kk = k; kk < k_end; ++kk) rmax = std::max(rmax, class_rmax[kk]);
+                for (uint32_t rk = lo; rk < hi; ++rk)  // the longest haplotype of the bin: first occupied slot of a class
+                    for (uint32_t d = 0; d < hrange; ++d)
+                        if (hist[(uint64_t)rk * hrange + d + 1] > hist[(uint64_t)rk * hrange + d]) {
+                            hmax = std::max(hmax, max_hap - d);
+                            break;
+                        }
+                const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
+                const int id = bin_id_of_class(k);
+                bins.push_back(Bin{id < 17 ? id : 0, first, end - first, plane_words, hmax, rmax, queue_of_bin(id, queue_per_class)});
+            }
+            k = k_end;
+        }
+        if (T > 1) {
+            // stable scatter: inside a slot thread 0's pairs come first, then thread 1's, ... -- the order one thread gives
+            for (uint64_t i = 0; i < table; ++i) {
+                uint32_t run = hist[i];
+                for (unsigned t = 0; t < T; ++t) {
+                    const uint32_t cnt = th_hist[t][i];
+                    th_hist[t][i] = run;
+                    run += cnt;
+                }
+            }
+            parallel_ranges(n_pairs, T, [&](uint64_t lo, uint64_t hi, unsigned t) {
+                uint32_t *start = th_hist[t].data();
+                for (uint64_t p = lo; p < hi; ++p) order[start[slot[p]]++] = (uint32_t)p;
+            });
+        }
+        else {
+            for (uint64_t p = 0; p < n_pairs; ++p) order[hist[slot[p]]++] = (uint32_t)p;
+        }
+    }
+    else {
+        // sparse length distribution: comparison sort on (class, length, index)
+        std::vector<uint64_t> keys(n_pairs);
+        for (uint64_t p = 0; p < n_pairs; ++p) {
+            uint32_t r, h;
+            if (cross) {
+                r = (uint32_t)(p / b->n_haps);
+                h = (uint32_t)(p % b->n_haps);
+            }
+            else {
+                r = b->pair_read[p] - read_bias;
+                h = b->pair_hap[p] - hap_bias;
+                if (r >= b->n_reads || h >= b->n_haps)
+                    return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)p);
+            }
+            pr[p] = r;
+            ph[p] = h;
+            const uint32_t R = b->read_len[r], H = b->hap_len[h];
+            cells += (uint64_t)R * H;
+            keys[p] = ((uint64_t)class_of(R, H) << 56) | ((uint64_t)(0xFFFFFu - H) << 32) | p;  // H < 2^20
+        }
+        std::sort(keys.begin(), keys.end());
+        for (uint64_t i = 0; i < n_pairs; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+        for (uint64_t i = 0; i < n_pairs;) {
+            const int id = bin_id_of_class((uint32_t)(keys[i] >> 56));
+            uint64_t j = i;
+            uint32_t hmax = 0, rmax = 0;
+            while (j < n_pairs && bin_id_of_class((uint32_t)(keys[j] >> 56)) == id) {
+                hmax = std::max(hmax, b->hap_len[ph[order[j]]]);
+                rmax = std::max(rmax, b->read_len[pr[order[j]]]);
+                ++j;
+            }
+            const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
+            bins.push_back(Bin{id < 17 ? id : 0, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax, queue_of_bin(id, queue_per_class)});
+            i = j;
+        }
+    }
+    *cells_out = cells;
+    return PHMM_OK;
+}
+
+int bin_regions(const phmm_region *regions, uint32_t n_regions, const uint32_t *read_len, uint32_t n_reads, const uint32_t *hap_len,
+                uint32_t n_haps, uint32_t *slot_first, uint32_t *pair_first, std::vector<Bin> &bins, uint64_t *cells_out, uint64_t *n_pairs_out)
+{
+    // pass 1: validate, count the pairs of every class, note each class's longest read and haplotype
+    uint64_t count[kClasses] = {0};
+    uint32_t class_rmax[kClasses] = {0}, class_hmax[kClasses] = {0};
+    uint64_t n_pairs = 0, cells = 0;
+    uint32_t next_read = 0;
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        const phmm_region &rg = regions[g];
+        if (rg.n_reads == 0 || rg.n_haps == 0) return fail(PHMM_E_INVALID, "region %u is empty", g);
+        if (rg.read_first < next_read || (uint64_t)rg.read_first + rg.n_reads > n_reads)
+            return fail(PHMM_E_INVALID, "region %u: reads [%u, +%u) overlap the region before or leave the table of %u", g, rg.read_first,
+                        rg.n_reads, n_reads);
+        if ((uint64_t)rg.hap_first + rg.n_haps > n_haps)
+            return fail(PHMM_E_INVALID, "region %u: haplotypes [%u, +%u) leave the table of %u", g, rg.hap_first, rg.n_haps, n_haps);
+        next_read = rg.read_first + rg.n_reads;
+        uint32_t hmax = 0;
+        uint64_t hsum = 0;
+        for (uint32_t h = rg.hap_first; h < rg.hap_first + rg.n_haps; ++h) {
+            hmax = std::max(hmax, hap_len[h]);
+            hsum += hap_len[h];
+        }
+        pair_first[g] = (uint32_t)n_pairs;
+        n_pairs += (uint64_t)rg.n_reads * rg.n_haps;
+        if (n_pairs > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "more than 2^32 pairs in one batch");
+        for (uint32_t r = rg.read_first; r < rg.read_first + rg.n_reads; ++r) {
+            const uint32_t k = class_of(read_len[r], hmax);  // (one class per read: a long haplotype sends the whole region to the striped kernel)
+            count[k] += rg.n_haps;
+            class_rmax[k] = std::max(class_rmax[k], read_len[r]);
+            class_hmax[k] = std::max(class_hmax[k], hmax);
+            cells += (uint64_t)read_len[r] * hsum;
+        }
+    }
+    // launches: classes 1..16 one each, the striped classes in four size ranges -- the rule of bin_pairs
+    const bool queue_per_class = queue_per_class_for(n_pairs);
+    uint32_t cursor[kClasses];
+    uint64_t run = 0;
+    for (uint32_t k = 0; k < kClasses; ++k) {
+        cursor[k] = (uint32_t)run;
+        run += count[k];
+    }
+    for (uint32_t k = 1; k < kClasses;) {
+        uint32_t k_end = k + 1;
+        while (k_end < kClasses && bin_id_of_class(k_end) == bin_id_of_class(k)) ++k_end;
+        uint64_t n = 0;
+        uint32_t hmax = 0, rmax = 0;
+        for (uint32_t kk = k; kk < k_end; ++kk) {
+            n += count[kk];
+            hmax = std::max(hmax, class_hmax[kk]);
+            rmax = std::max(rmax, class_rmax[kk]);
+        }
+        if (n) {
+            const int id = bin_id_of_class(k);
+            bins.push_back(Bin{id < 17 ? id : 0, cursor[k], (uint32_t)n, (uint32_t)phmm::kPlanes * phmm::planes_words(hmax), hmax, rmax,
+                               queue_of_bin(id, queue_per_class)});
+        }
+        k = k_end;
+    }
+    // pass 2: every read's run of `order`
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        const phmm_region &rg = regions[g];
+        uint32_t hmax = 0;
+        for (uint32_t h = rg.hap_first; h < rg.hap_first + rg.n_haps; ++h) hmax = std::max(hmax, hap_len[h]);
+        for (uint32_t r = rg.read_first; r < rg.read_first + rg.n_reads; ++r) {
+            const uint32_t k = class_of(read_len[r], hmax);
+            slot_first[r] = cursor[k];
+            cursor[k] += rg.n_haps;
+        }
+    }
+    *cells_out = cells;
+    *n_pairs_out = n_pairs;
+    return PHMM_OK;
+}
+
+}  // namespace phmm_detail

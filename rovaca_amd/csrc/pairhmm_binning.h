@@ -1,0 +1,130 @@
+// pairhmm_binning.h -- the length binning of a batch: which kernel shape every pair takes and in which order the pairs are
+// processed.  Host only (no HIP call), shared by the pair-list upload (pairhmm_capi.cpp) and the region-descriptor path
+// (pairhmm_stage.cpp); phmm_plan_bins / phmm_plan_region_bins in the C ABI expose it to the CPU-side tests.
+#ifndef ROVACA_AMD_PAIRHMM_BINNING_H_
+#define ROVACA_AMD_PAIRHMM_BINNING_H_
+#include <algorithm>
+#include <cstdint>
+#include <thread>
+#include <vector>
+
+#include "../../include/pairhmm_hip.h"
+#include "pairhmm_device.h"
+
+struct Bin
+{
+    int rows_per_lane;      // 1..16: single-pass kernel <K>; 0: striped kernel (long read or long haplotype)
+    uint32_t first, count;  // range of `order`
+    uint32_t lds_words_per_group;
+    uint32_t max_hap_len, max_read_len;
+    int queue;              // rescue queue the launch feeds (phmm::kRescueQueues)
+};
+
+// Striped pairs are launched in up to four size ranges (48+ stripes of 128 rows, 24..47, 8..23, 1..7), each with the team
+// shape that fits it: a batch of a thousand long reads of very different sizes is otherwise bound by its longest pair
+// sweeping alone in a team sized for the average one.  Length classes: 1..16 single-pass rows per lane, then
+// 17 + 63 - min(stripes, 63).
+constexpr int kQueues = phmm::kRescueQueues;
+static inline int bin_id_of_class(uint32_t k) { return k < 17 ? (int)k : k < 33 ? 17 : k < 57 ? 18 : k < 73 ? 19 : 20; }
+
+// single-pass kernels keep 16 pairs' haplotype planes in LDS per workgroup; longer haplotypes take the striped kernel
+constexpr uint32_t kSinglePassMaxHap = 4096;
+constexpr uint32_t kMaxLen = 1u << 20;
+constexpr uint64_t kQueuePerClassMinPairs = 50000;  // batches above this re-run each single-pass class from its own queue
+constexpr uint32_t kXcdLocalMinPairs = 1u << 18;  // single-pass launches from this many pairs on order their workgroups XCD-locally
+constexpr uint32_t kWideMaxPairs = 1536;       // single-pass launches up to this many pairs run one pair per wave
+constexpr uint32_t kRescueMaxTeams = 4096;    // workgroups of the fp64 re-run (they stride over the rescue queue)
+constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
+
+
+// Test and tuning hooks are environment variables named PHMM_*, looked up where they apply so that a test can flip them between
+// calls.  A production process has none: an entry point on the latency-critical path (phmm_stage_submit, phmm_compute) opens a
+// HookScope, which scans the environment ONCE for the prefix, and every phmm_hook() inside it is then a thread-local flag test
+// instead of a getenv (a dozen of them cost a region-sized submission 3-5 us).  Outside a scope phmm_hook is plain getenv.
+namespace phmm_detail
+{
+extern thread_local int t_hooks;  // -1: no scope open (look up); 0: the environment has no PHMM_* variable; 1: it has
+bool any_phmm_variable();
+struct HookScope
+{
+    int saved;
+    HookScope() : saved(t_hooks) { if (t_hooks < 0) t_hooks = any_phmm_variable() ? 1 : 0; }
+    ~HookScope() { t_hooks = saved; }
+    HookScope(const HookScope &) = delete;
+    HookScope &operator=(const HookScope &) = delete;
+};
+}  // namespace phmm_detail
+const char *phmm_hook(const char *name);
+
+// Length class of a pair: rows per lane 1..16 for the single-pass kernels (one launch each); pairs with a read above 256 bases
+// or a haplotype above the single-pass LDS budget go to the striped kernel, most stripes first
+constexpr uint32_t kClasses = 17 + 64;  // 1..16, then 17 + 63 - min(stripes, 63)
+static inline uint32_t class_of(uint32_t R, uint32_t H)
+{
+    const uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
+    if (K > (uint32_t)phmm::kMaxRowsPerLane || H > kSinglePassMaxHap) {
+        const uint32_t S = phmm::kLanesPerPair * phmm::kStripedRowsF32;
+        return 17u + (63u - std::min<uint32_t>((R + S - 1) / S, 63u));  // most stripes first: the longest pairs start first
+    }
+    return K;
+}
+// Rescue queue of a bin.  A large batch gives every single-pass class its own queue: the fp64 re-run of a queue is one launch
+// whose waves hold four pairs each, and pairs of one class (read lengths within 16, haplotypes arriving longest first) keep
+// those four in step -- mixed lengths in one queue cost the re-run a quarter of its rate.  A small batch keeps one queue: a
+// launch per class would add more latency than the divergence costs.
+static inline int queue_of_bin(int bin_id, bool queue_per_class) { return bin_id >= 17 ? bin_id - 16 : queue_per_class ? 4 + bin_id : 0; }
+bool queue_per_class_for(uint64_t n_pairs);  // n_pairs > kQueuePerClassMinPairs, or PHMM_FORCE_QUEUE_PER_CLASS (tests)
+
+// Host loops over the pairs of a BIG batch (binning, the final log10) are split over a few threads; a region-sized call
+// never gets here.
+constexpr uint64_t kParallelMinPairs = 1u << 17;
+template <typename F>
+static void parallel_ranges(uint64_t n, unsigned n_threads, F &&fn)  // fn(lo, hi, thread index)
+{
+    std::vector<std::thread> th;
+    th.reserve(n_threads);
+    unsigned started = 1;  // ranges [1, started) run on helper threads; the rest on the caller (a process with 128 workers may
+                           // be out of threads: std::thread then throws, and the work is done here instead)
+    try {
+        for (; started < n_threads; ++started) {
+            const unsigned t = started;
+            th.emplace_back([&fn, n, n_threads, t] { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
+        }
+    }
+    catch (...) {
+    }
+    fn(0, n / n_threads, 0u);
+    for (unsigned t = started; t < n_threads; ++t) fn(n * t / n_threads, n * (t + 1) / n_threads, t);
+    for (auto &x : th) x.join();
+}
+static unsigned host_threads()
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(8u, hw ? hw : 1u));
+}
+
+
+namespace phmm_detail
+{
+struct BinScratch  // host scratch of the pair binning, kept between calls by its owner
+{
+    std::vector<uint32_t> hist, slot;
+};
+// Pair-list form.  Order = (class, haplotype length descending, pair index), as a counting sort over (class, length) -- a
+// comparison sort was the largest host cost of a region-sized call -- or a comparison sort when the lengths are sparse.
+// cross: the pair list is the full cross product in (read, hap) order and pair_read / pair_hap are not read.  read_bias /
+// hap_bias are subtracted from the indices of a pair list that counts from the start of the caller's tables while b's tables
+// are windows of them.  Writes pr[p], ph[p] (the pair list as the kernels index it) and order[0 .. n_pairs), appends the
+// launches to `bins`.  PHMM_E_INVALID (with the message set) when a pair indexes outside the tables.
+int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_bias, uint32_t hap_bias, uint32_t *pr, uint32_t *ph,
+              uint32_t *order, BinScratch &scratch, std::vector<Bin> &bins, uint64_t *cells);
+
+// Region form: every region is the cross product of a run of reads with a run of haplotypes, so the placement is decided per
+// READ (O(reads) host work; the pair list itself is spelled out on the device): order = (class, region, read, hap), and
+// slot_first[r] is the position in `order` of read r's first pair, pair_first[g] the id of region g's first pair (pair ids
+// count region by region, [read][hap] inside one).  Regions must list their reads in ascending, non-overlapping runs;
+// haplotypes may be shared.  A region with a haplotype above the single-pass budget sends all its pairs to the striped kernel.
+int bin_regions(const phmm_region *regions, uint32_t n_regions, const uint32_t *read_len, uint32_t n_reads, const uint32_t *hap_len,
+                uint32_t n_haps, uint32_t *slot_first, uint32_t *pair_first, std::vector<Bin> &bins, uint64_t *cells, uint64_t *n_pairs);
+}  // namespace phmm_detail
+#endif

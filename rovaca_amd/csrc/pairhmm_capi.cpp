@@ -23,9 +23,10 @@
 #include "pairhmm_device.h"
 #include "pairhmm_tables.h"
 
-namespace
-{
+#include "pairhmm_engine.h"
 
+namespace phmm_detail
+{
 thread_local char g_err[512] = "";
 
 int fail(int code, const char *fmt, ...)
@@ -36,249 +37,8 @@ int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
-
-#define HIP_TRY(expr)                                                                                          \
-    do {                                                                                                       \
-        hipError_t e__ = (expr);                                                                               \
-        if (e__ != hipSuccess) return fail(PHMM_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));        \
-    } while (0)
-
-template <typename T>
-struct DevBuf
-{
-    T *p = nullptr;
-    size_t n = 0;    // elements in use
-    size_t cap = 0;  // elements allocated (grow-only, so a context's scratch batch stops allocating after a few calls)
-    DevBuf() = default;
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { reset(); }
-    void reset()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = cap = 0;
-    }
-    hipError_t alloc(size_t count)
-    {
-        if (count <= cap) {
-            n = count;
-            return hipSuccess;
-        }
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = cap = 0;
-        const size_t want = count + count / 4 + 64;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
-        if (e != hipSuccess) return e;
-        cap = want;
-        n = count;
-        return hipSuccess;
-    }
-    hipError_t upload(const T *src, size_t count, hipStream_t s)
-    {
-        hipError_t e = alloc(count);
-        if (e != hipSuccess || count == 0) return e;
-        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
-    }
-};
-
-// a typed window into the resident batch's single input blob (not owned)
-template <typename T>
-struct DevView
-{
-    T *p = nullptr;
-    size_t n = 0;
-};
-
-// pinned host staging, grow-only
-struct HostBuf
-{
-    void *p = nullptr;
-    size_t cap = 0;
-    HostBuf() = default;
-    HostBuf(const HostBuf &) = delete;
-    HostBuf &operator=(const HostBuf &) = delete;
-    ~HostBuf()
-    {
-        if (p) (void)hipHostFree(p);
-    }
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        const size_t want = bytes + bytes / 4 + 4096;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e != hipSuccess) return e;
-        cap = want;
-        return hipSuccess;
-    }
-};
-
-}  // namespace
-
-struct phmm_context
-{
-    // BASELINE config 1: a context made by phmm_create_cpu computes on the host (pairhmm_cpu.cpp) and owns no HIP object
-    bool cpu = false;
-    unsigned cpu_threads = 1;
-    bool cpu_simd = true;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    DevBuf<float> ph2pr_f32, mm_f32;
-    DevBuf<double> ph2pr_f64, mm_f64;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // the per-K launches of one pass are independent: they are spread over a few side streams so that the tail of one
-    // launch overlaps the head of the next (mixed-length batches have up to 17 launches per pass)
-    static constexpr int kSideStreams = 3;  // created
-    int n_side = 2;                         // used (PHMM_SIDE_STREAMS overrides: tuning; 2 and 3 measure the same, 0 loses 40 % on config 5)
-    hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
-    struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
-    // big one-shot batches are cut into chunks that alternate between two resident slots: chunk k + 1 is binned, packed and
-    // uploaded (on side[2]) while chunk k is swept, chunk k - 1 finalised on the host meanwhile
-    struct phmm_resident *chunk_slot[2] = {nullptr, nullptr};
-    hipEvent_t chunk_up[2] = {nullptr, nullptr}, chunk_done[2] = {nullptr, nullptr};
-    std::vector<uint32_t> bin_hist, bin_slot;  // host scratch of the length binning, kept between calls
-    std::vector<hipEvent_t> timing;            // event pool of phmm_sweep_timed
-    DevBuf<uint8_t> marg_dev;                  // phmm_marginalize: [old matrix][index map][result]
-    HostBuf marg_stage;
-};
-
-struct Bin
-{
-    int rows_per_lane;      // 1..16: single-pass kernel <K>; 0: striped kernel (long read or long haplotype)
-    uint32_t first, count;  // range of `order`
-    uint32_t lds_words_per_group;
-    uint32_t max_hap_len, max_read_len;
-    int queue;              // rescue queue the launch feeds (phmm::kRescueQueues)
-};
-
-// Striped pairs are launched in up to four size ranges (48+ stripes of 128 rows, 24..47, 8..23, 1..7), each with the team
-// shape that fits it: a batch of a thousand long reads of very different sizes is otherwise bound by its longest pair
-// sweeping alone in a team sized for the average one.  Length classes: 1..16 single-pass rows per lane, then
-// 17 + 63 - min(stripes, 63).
-constexpr int kQueues = phmm::kRescueQueues;
-static inline int bin_id_of_class(uint32_t k) { return k < 17 ? (int)k : k < 33 ? 17 : k < 57 ? 18 : k < 73 ? 19 : 20; }
-
-// Geometry of a striped launch.  lanes: 16 puts four pairs in a wave, 64 gives a whole wave to one pair (chosen when the
-// launch has so few pairs that four-per-wave would leave most of the chip idle and the reads are long enough to fill 64-lane
-// stripes).  waves: how many waves pipeline the stripes of the same pairs -- enough stripes to keep them busy, a haplotype
-// long enough for the pipeline lag (4 or 6 supersteps of 32 columns per wave), and only when the batch is small.
-struct TeamShape
-{
-    int lanes, waves;
-};
-static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t max_hap, uint32_t rows_per_lane)
-{
-    TeamShape sh{16, 1};
-    if ((n_pairs + 3) / 4 < 1024 && max_read > 64u * rows_per_lane) sh.lanes = 64;
-    // long reads take a wave each whatever the batch size: the zero-superstep shortcut works per wave, and four pairs in a
-    // wave are rarely all zero at the same columns (measured on 6 000 pairs of 2 000 x 2 400: fp32 4.7 -> 3.5 ms, fp64 15.7
-    // -> 12.9 ms; on 1 000 x 1 200 the fp64 re-run gains, the fp32 sweep does not)
-    if (max_read >= (rows_per_lane >= 8 ? 1536u : 768u)) sh.lanes = 64;
-    if (const char *f = getenv("PHMM_FORCE_TEAM_LANES")) {  // tests
-        const int l = atoi(f);
-        if (l == 16 || l == 64) sh.lanes = l;
-    }
-    const uint32_t per_wave = 64u / (uint32_t)sh.lanes;
-    const uint32_t batches = (n_pairs + per_wave - 1) / per_wave;
-    // teams of several waves run the band kernel, whose stripes are kBandRows rows per lane tall whatever the one-wave shape is
-    const uint32_t stripes = (max_read + sh.lanes * phmm::kBandRows - 1) / (sh.lanes * phmm::kBandRows);
-    const uint32_t supersteps = (max_hap + (uint32_t)sh.lanes - 1 + 31) / 32;
-    const uint32_t lag = sh.lanes == 64 ? 6u : 4u;  // team_lag<G>() of the kernel
-    // (one pair per wave: since all-zero supersteps are skipped only one or two waves of a team have work at any time, and
-    // eight waves per pair measured slower than four on config 5)
-    if (sh.lanes == 16 && batches < 2048 && stripes >= 8 && supersteps >= lag * 8 + 12)
-        sh.waves = 8;
-    else if (batches < 4096 && stripes >= 4 && supersteps >= lag * 4 + 12)
-        sh.waves = 4;
-    if (const char *f = getenv("PHMM_FORCE_TEAM_WAVES")) {  // tests: exercise every team width on small batches
-        const int w = atoi(f);
-        if ((w == 1 || w == 4 || w == 8) && supersteps >= lag * w + 12u) sh.waves = w;
-    }
-    return sh;
-}
-
-// single-pass kernels keep 16 pairs' haplotype planes in LDS per workgroup; longer haplotypes take the striped kernel
-constexpr uint32_t kSinglePassMaxHap = 4096;
-constexpr uint32_t kMaxLen = 1u << 20;
-constexpr uint64_t kQueuePerClassMinPairs = 50000;  // batches above this re-run each single-pass class from its own queue
-constexpr uint32_t kXcdLocalMinPairs = 1u << 18;  // single-pass launches from this many pairs on order their workgroups XCD-locally
-constexpr uint32_t kWideMaxPairs = 1536;       // single-pass launches up to this many pairs run one pair per wave
-constexpr uint32_t kRescueMaxTeams = 4096;    // workgroups of the fp64 re-run (they stride over the rescue queue)
-constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
-
-// a batch kept by a CPU context: deep copies of the tables (prepared: H3/H4 already applied when the batch asked for it)
-struct CpuBatch
-{
-    std::vector<uint8_t> bases, qual, ins, del, gcp, haps;
-    std::vector<uint32_t> roff, rlen, hoff, hlen, pr, ph;
-    std::vector<float> raw32;
-    std::vector<double> raw64;
-    std::vector<uint8_t> rescued;
-    phmm_batch view{};
-};
-
-struct phmm_resident
-{
-    CpuBatch *cpu = nullptr;
-    ~phmm_resident() { delete cpu; }
-    uint64_t n_pairs = 0, cells = 0;
-    uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
-    bool uniform_gcp = false, uniform_gop = false;
-    // inputs travel as ONE pinned staging buffer and ONE host-to-device copy per upload (a region-sized submission is
-    // latency-bound: fifteen small copies cost more than the sweep); the views below point into `blob`
-    HostBuf stage, out_stage;
-    DevBuf<uint8_t> blob;
-    DevView<uint8_t> read_bases, read_qual, hap_bases, read_mapq;
-    DevView<uint32_t> read_off, read_len, hap_off, hap_len, pair_read, pair_hap, order, plane_off, word_owner;
-    DevView<uint8_t> read_ins, read_del, read_gcp;  // prepared batches: inside `blob`; otherwise the two buffers below
-    DevBuf<uint8_t> prep_gop, prep_gcp;             // written by the set-up launch (device-side read preparation)
-    DevBuf<uint32_t> planes;
-    DevBuf<float> raw32;
-    DevBuf<double> raw64;
-    DevBuf<uint32_t> rescue_list;
-    DevView<uint32_t> rescue_count;  // inside raw32, behind the sums
-    bool queue_is_empty = false;     // the set-up launch has just zeroed rescue_count
-    DevBuf<float> carry32;
-    DevBuf<double> carry64;
-    std::vector<Bin> bins;
-    uint32_t last_rescued = 0;
-    double last_kernel_ms = 0.0;
-};
-
-// Host loops over the pairs of a BIG batch (binning, the final log10) are split over a few threads; a region-sized call
-// never gets here.
-constexpr uint64_t kParallelMinPairs = 1u << 17;
-template <typename F>
-static void parallel_ranges(uint64_t n, unsigned n_threads, F &&fn)  // fn(lo, hi, thread index)
-{
-    std::vector<std::thread> th;
-    th.reserve(n_threads);
-    unsigned started = 1;  // ranges [1, started) run on helper threads; the rest on the caller (a process with 128 workers may
-                           // be out of threads: std::thread then throws, and the work is done here instead)
-    try {
-        for (; started < n_threads; ++started) {
-            const unsigned t = started;
-            th.emplace_back([&fn, n, n_threads, t] { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
-        }
-    }
-    catch (...) {
-    }
-    fn(0, n / n_threads, 0u);
-    for (unsigned t = started; t < n_threads; ++t) fn(n * t / n_threads, n * (t + 1) / n_threads, t);
-    for (auto &x : th) x.join();
-}
-static unsigned host_threads()
-{
-    const unsigned hw = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(8u, hw ? hw : 1u));
-}
-
+}  // namespace phmm_detail
+using phmm_detail::g_err;
 
 // The entry points are implemented in this namespace with C++ linkage; the extern "C" wrappers at the end of the file
 // catch whatever a body may throw (std::bad_alloc from a vector, std::system_error from a thread), so that nothing
@@ -367,6 +127,8 @@ int phmm_create_cpu(int n_threads, int allow_simd, phmm_context **out)
 void phmm_destroy(phmm_context *c)
 {
     if (!c) return;
+    impl::phmm_stage_destroy(c, c->region_stage);
+    c->region_stage = nullptr;
     if (c->cpu) {
         delete c->scratch;
         delete c;
@@ -509,7 +271,7 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, 
         ugo = ug && (gop_diff & 127) == 0;
     }
     rb->uniform_gcp = ug;
-    rb->uniform_gop = ug && ugo && !getenv("PHMM_NO_UNIFORM_GOP");  // (the variable: tests compare the two kernels)
+    rb->uniform_gop = ug && ugo && !phmm_hook("PHMM_NO_UNIFORM_GOP");  // (the variable: tests compare the two kernels)
     // In the Rovaca case two of the five read arrays carry no information: the deletion gap-opens are the insertion ones and
     // the gap-continuation array is one value.  They are not packed or copied: on the device `del` aliases `ins` and `gcp` is
     // a fill (a big one-shot batch spends more host time packing tables than binning pairs).
@@ -584,177 +346,11 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, 
     }
     PHASE(1);
 
-    // ---- pair list (materialise the cross product) and length binning ----
-    // Order = (class, haplotype length descending, pair index).  Class = rows per lane 1..16 for the single-pass kernels
-    // (one launch each, waves of near-equal sweep length, the longest first so that the tail is short); pairs with a read
-    // above 256 bases or a haplotype above the single-pass LDS budget go to the striped kernel, most stripes first (longest-job-first fills the chip best).
-    // Done as a counting sort over (class, length): a comparison sort was the largest host cost of a region-sized call.
-    constexpr uint32_t kClasses = 17 + 64;  // 1..16, then 17 + 63 - min(stripes, 63)
-    // Rescue queue of a bin.  A large batch gives every single-pass class its own queue: the fp64 re-run of a queue is one
-    // launch whose waves hold four pairs each, and pairs of one class (read lengths within 16, haplotypes arriving longest
-    // first) keep those four in step -- mixed lengths in one queue cost the re-run a quarter of its rate.  A small batch
-    // keeps one queue: a launch per class would add more latency than the divergence costs.
-    const bool queue_per_class = n_pairs > kQueuePerClassMinPairs || getenv("PHMM_FORCE_QUEUE_PER_CLASS") != nullptr;
-    auto queue_of = [&](int id) { return id >= 17 ? id - 16 : queue_per_class ? 4 + id : 0; };
-    auto class_of = [](uint32_t R, uint32_t H) -> uint32_t {
-        const uint32_t K = (R + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
-        if (K > (uint32_t)phmm::kMaxRowsPerLane || H > kSinglePassMaxHap) {
-            const uint32_t S = phmm::kLanesPerPair * phmm::kStripedRowsF32;
-            return 17u + (63u - std::min<uint32_t>((R + S - 1) / S, 63u));  // most stripes first: the longest pairs start first
-        }
-        return K;
-    };
-    uint32_t min_hap = max_hap;
-    for (uint32_t h = 0; h < b->n_haps; ++h) min_hap = std::min(min_hap, b->hap_len[h]);
-    const uint32_t hrange = b->n_haps ? max_hap - min_hap + 1 : 1;
-    uint32_t rank[kClasses], n_used = 0, class_rmax[kClasses];
-    {
-        bool used[kClasses] = {false};
-        const bool long_hap = max_hap > kSinglePassMaxHap;
-        for (uint32_t r = 0; r < b->n_reads; ++r) {
-            used[class_of(b->read_len[r], 1)] = true;
-            if (long_hap) used[class_of(b->read_len[r], max_hap)] = true;
-        }
-        for (uint32_t k = 0; k < kClasses; ++k) {
-            rank[k] = n_used;
-            class_rmax[k] = 0;
-            if (used[k]) ++n_used;
-        }
-    }
+    // ---- pair list (materialise the cross product) and length binning: pairhmm_binning.cpp ----
     uint64_t cells = 0;
-    const uint64_t table = (uint64_t)n_used * hrange;
-    if (table <= std::max<uint64_t>(4 * n_pairs, 1u << 16)) {
-        std::vector<uint32_t> &hist = c->bin_hist, &slot = c->bin_slot;
-        hist.assign(table + 1, 0);
-        slot.resize(n_pairs);
-        const unsigned T = (n_pairs >= kParallelMinPairs && table <= (1u << 16)) ? host_threads() : 1u;
-        std::vector<std::vector<uint32_t>> th_hist(T > 1 ? T : 0);
-        std::vector<uint64_t> th_cells(T, 0);
-        std::vector<uint32_t> th_rmax((size_t)T * kClasses, 0);
-        std::atomic<uint64_t> bad_pair{UINT64_MAX};
-        auto count_range = [&](uint64_t lo, uint64_t hi, unsigned t) {
-            uint32_t *h_t = T > 1 ? th_hist[t].data() : hist.data() + 1;  // one thread counts straight into hist[at + 1]
-            uint32_t *rmax_t = th_rmax.data() + (size_t)t * kClasses;
-            uint64_t cells_t = 0;
-            for (uint64_t p = lo; p < hi; ++p) {
-                uint32_t r, h;
-                if (cross) {
-                    r = (uint32_t)(p / b->n_haps);
-                    h = (uint32_t)(p % b->n_haps);
-                }
-                else {
-                    r = b->pair_read[p] - opt.read_bias;  // (an index below the bias wraps and fails the range check)
-                    h = b->pair_hap[p] - opt.hap_bias;
-                    if (r >= b->n_reads || h >= b->n_haps) {
-                        uint64_t expect = UINT64_MAX;
-                        bad_pair.compare_exchange_strong(expect, p);
-                        return;
-                    }
-                }
-                const uint32_t R = b->read_len[r], H = b->hap_len[h];
-                const uint32_t k = class_of(R, H);
-                rmax_t[k] = std::max(rmax_t[k], R);
-                const uint32_t at = rank[k] * hrange + (max_hap - H);
-                pr[p] = r;
-                ph[p] = h;
-                slot[p] = at;
-                ++h_t[at];
-                cells_t += (uint64_t)R * H;
-            }
-            th_cells[t] = cells_t;
-        };
-        if (T > 1) {
-            for (auto &v : th_hist) v.assign(table, 0);
-            parallel_ranges(n_pairs, T, count_range);
-            for (unsigned t = 0; t < T; ++t)
-                for (uint64_t i = 0; i < table; ++i) hist[i + 1] += th_hist[t][i];
-        }
-        else {
-            count_range(0, n_pairs, 0);
-        }
-        if (bad_pair.load() != UINT64_MAX)
-            return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)bad_pair.load());
-        for (unsigned t = 0; t < T; ++t) {
-            cells += th_cells[t];
-            for (uint32_t k = 0; k < kClasses; ++k) class_rmax[k] = std::max(class_rmax[k], th_rmax[(size_t)t * kClasses + k]);
-        }
-        for (uint64_t i = 0; i < table; ++i) hist[i + 1] += hist[i];  // hist[i] = first position of slot i
-        // bins: classes 1..16 one each, the striped classes in four size ranges
-        for (uint32_t k = 1; k < kClasses;) {
-            uint32_t k_end = k + 1;
-            while (k_end < kClasses && bin_id_of_class(k_end) == bin_id_of_class(k)) ++k_end;
-            const uint32_t lo = rank[k], hi = k_end < kClasses ? rank[k_end] : n_used;
-            const uint32_t first = hist[(uint64_t)lo * hrange], end = hist[(uint64_t)hi * hrange];
-            if (end > first) {
-                uint32_t hmax = 0, rmax = 0;
-                for (uint32_t kk = k; kk < k_end; ++kk) rmax = std::max(rmax, class_rmax[kk]);
-                for (uint32_t rk = lo; rk < hi; ++rk)  // the longest haplotype of the bin: first occupied slot of a class
-                    for (uint32_t d = 0; d < hrange; ++d)
-                        if (hist[(uint64_t)rk * hrange + d + 1] > hist[(uint64_t)rk * hrange + d]) {
-                            hmax = std::max(hmax, max_hap - d);
-                            break;
-                        }
-                const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
-                const int id = bin_id_of_class(k);
-                rb->bins.push_back(Bin{id < 17 ? id : 0, first, end - first, plane_words, hmax, rmax, queue_of(id)});
-            }
-            k = k_end;
-        }
-        if (T > 1) {
-            // stable scatter: inside a slot thread 0's pairs come first, then thread 1's, ... -- the order one thread gives
-            for (uint64_t i = 0; i < table; ++i) {
-                uint32_t run = hist[i];
-                for (unsigned t = 0; t < T; ++t) {
-                    const uint32_t cnt = th_hist[t][i];
-                    th_hist[t][i] = run;
-                    run += cnt;
-                }
-            }
-            parallel_ranges(n_pairs, T, [&](uint64_t lo, uint64_t hi, unsigned t) {
-                uint32_t *start = th_hist[t].data();
-                for (uint64_t p = lo; p < hi; ++p) order[start[slot[p]]++] = (uint32_t)p;
-            });
-        }
-        else {
-            for (uint64_t p = 0; p < n_pairs; ++p) order[hist[slot[p]]++] = (uint32_t)p;
-        }
-    }
-    else {
-        // sparse length distribution: comparison sort on (class, length, index)
-        std::vector<uint64_t> keys(n_pairs);
-        for (uint64_t p = 0; p < n_pairs; ++p) {
-            uint32_t r, h;
-            if (cross) {
-                r = (uint32_t)(p / b->n_haps);
-                h = (uint32_t)(p % b->n_haps);
-            }
-            else {
-                r = b->pair_read[p] - opt.read_bias;
-                h = b->pair_hap[p] - opt.hap_bias;
-                if (r >= b->n_reads || h >= b->n_haps)
-                    return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)p);
-            }
-            pr[p] = r;
-            ph[p] = h;
-            const uint32_t R = b->read_len[r], H = b->hap_len[h];
-            cells += (uint64_t)R * H;
-            keys[p] = ((uint64_t)class_of(R, H) << 56) | ((uint64_t)(0xFFFFFu - H) << 32) | p;  // H < 2^20
-        }
-        std::sort(keys.begin(), keys.end());
-        for (uint64_t i = 0; i < n_pairs; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
-        for (uint64_t i = 0; i < n_pairs;) {
-            const int id = bin_id_of_class((uint32_t)(keys[i] >> 56));
-            uint64_t j = i;
-            uint32_t hmax = 0, rmax = 0;
-            while (j < n_pairs && bin_id_of_class((uint32_t)(keys[j] >> 56)) == id) {
-                hmax = std::max(hmax, b->hap_len[ph[order[j]]]);
-                rmax = std::max(rmax, b->read_len[pr[order[j]]]);
-                ++j;
-            }
-            const uint32_t plane_words = (uint32_t)phmm::kPlanes * phmm::planes_words(hmax);
-            rb->bins.push_back(Bin{id < 17 ? id : 0, (uint32_t)i, (uint32_t)(j - i), plane_words, hmax, rmax, queue_of(id)});
-            i = j;
-        }
+    {
+        const int rc = phmm_detail::bin_pairs(b, cross, n_pairs, opt.read_bias, opt.hap_bias, pr, ph, order, c->bin_scratch, rb->bins, &cells);
+        if (rc != PHMM_OK) return rc;
     }
     rb->cells = cells;
     PHASE(2);
@@ -906,7 +502,7 @@ static int cpu_keep(const phmm_batch *b, CpuBatch *k)
     return PHMM_OK;
 }
 
-static int cpu_upload(phmm_context *, const phmm_batch *b, phmm_resident *rb)
+int cpu_upload(phmm_context *, const phmm_batch *b, phmm_resident *rb)
 {
     uint64_t n = 0;
     int rc = cpu_check_batch(b, &n);
@@ -925,7 +521,7 @@ static int cpu_upload(phmm_context *, const phmm_batch *b, phmm_resident *rb)
     return PHMM_OK;
 }
 
-static int cpu_sweep(phmm_context *c, phmm_resident *rb)
+int cpu_sweep(phmm_context *c, phmm_resident *rb)
 {
     if (!rb->cpu) return fail(PHMM_E_INVALID, "phmm_sweep: this batch was not uploaded through a CPU context");
     CpuBatch &k = *rb->cpu;
@@ -974,7 +570,7 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
     return PHMM_OK;
 }
 
-static int sweep_fp32(phmm_context *c, phmm_resident *rb)
+int sweep_fp32(phmm_context *c, phmm_resident *rb)
 {
     if (rb->n_pairs && !rb->queue_is_empty) HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, kQueues * sizeof(uint32_t), c->stream));
     rb->queue_is_empty = false;
@@ -1024,10 +620,10 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
         a.order = rb->order.p + bin.first;
         a.n_pairs = bin.count;
         a.lds_words_per_group = bin.lds_words_per_group;
-        a.no_early_exit = getenv("PHMM_NO_EARLY_EXIT") ? 1u : 0u;  // tests
+        a.no_early_exit = phmm_hook("PHMM_NO_EARLY_EXIT") ? 1u : 0u;  // tests
         a.ph2pr = c->ph2pr_f32.p;
         a.mm_table = c->mm_f32.p;
-        a.out_raw = rb->raw32.p;
+        a.out_raw = rb->out32_host ? static_cast<void *>(rb->out32_host) : static_cast<void *>(rb->raw32.p);
         // underflowed pairs go to the queue of the bin's size range (queue 0 starts at 0, a striped range at its own first)
         a.rescue_list = rb->rescue_list.p + (bin.queue == 0 ? 0 : bin.first);
         a.rescue_count = rb->rescue_count.p + bin.queue;
@@ -1037,21 +633,23 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
             // steps) at 1.8x the instructions, which is free while SIMDs idle.  Measured: a 432-pair region 85 -> 46 us, 1728
             // pairs 86 -> 68 us, no gain from 4000 pairs on, and a loss when several submissions share the chip, hence the
             // low threshold.
-            int lanes = bin.count <= kWideMaxPairs ? 64 : 16;
-            if (const char *f = getenv("PHMM_FORCE_LANES")) {  // tests
+            uint32_t wide_max = kWideMaxPairs;
+            if (const char *f = phmm_hook("PHMM_WIDE_MAX_PAIRS")) wide_max = (uint32_t)std::max(0, atoi(f));  // tuning
+            int lanes = bin.count <= wide_max ? 64 : 16;
+            if (const char *f = phmm_hook("PHMM_FORCE_LANES")) {  // tests
                 const int l = atoi(f);
                 if (l == 16 || l == 64) lanes = l;
             }
             const int k = lanes == 64 ? (int)((bin.max_read_len + 63) / 64) : bin.rows_per_lane;
             // big four-pairs-per-wave launches: runs of 64 workgroups (1 024 pairs, a region or so) per XCD, see KernelArgs
             uint32_t xcd_min = kXcdLocalMinPairs;
-            if (const char *f = getenv("PHMM_XCD_LOCAL_MIN_PAIRS")) xcd_min = (uint32_t)std::max(1, atoi(f));  // tests: small launches too
-            if (lanes == 16 && bin.count >= xcd_min && !getenv("PHMM_NO_XCD_LOCAL_ORDER")) a.xcd_run_log2 = 6;
+            if (const char *f = phmm_hook("PHMM_XCD_LOCAL_MIN_PAIRS")) xcd_min = (uint32_t)std::max(1, atoi(f));  // tests: small launches too
+            if (lanes == 16 && bin.count >= xcd_min && !phmm_hook("PHMM_NO_XCD_LOCAL_ORDER")) a.xcd_run_log2 = 6;
             HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream, rb->uniform_gop));
             a.xcd_run_log2 = 0;
         }
         else if (bin.max_read_len <= 64u * phmm::kMaxRowsPerLaneWide && bin.max_hap_len <= kSinglePassMaxHap &&
-                 !getenv("PHMM_NO_WIDE_SINGLE_PASS")) {
+                 !phmm_hook("PHMM_NO_WIDE_SINGLE_PASS")) {
             // reads of 257..512 bases: still one pass, a whole wave per pair (no stripes, no carry): measured 20 % faster than
             // the team kernel on 400 x 600
             HIP_TRY(phmm::launch_systolic_f32((int)((bin.max_read_len + 63) / 64), 64, rb->uniform_gcp, a, stream, rb->uniform_gop));
@@ -1071,7 +669,7 @@ static int sweep_fp32(phmm_context *c, phmm_resident *rb)
     return PHMM_OK;
 }
 
-static int sweep_rescue(phmm_context *c, phmm_resident *rb)
+int sweep_rescue(phmm_context *c, phmm_resident *rb)
 {
     // The fp64 re-run of the pairs the fp32 kernels queued.  Nothing comes back to the host between the two passes: the
     // team kernel reads the queue length from device memory and its workgroups stride over the queue (all of them leave
@@ -1106,7 +704,7 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
         static const double rate[3] = {1.00, 1.12, 1.21};
         double best = 0.0;
         int forced = 0;
-        if (const char *f = getenv("PHMM_FORCE_F64_ROWS")) forced = atoi(f);  // tests
+        if (const char *f = phmm_hook("PHMM_FORCE_F64_ROWS")) forced = atoi(f);  // tests
         for (int k = phmm::kStripedRowsF64Min; k <= phmm::kStripedRowsF64Max; ++k) {
             const TeamShape cand = pick_team_shape(p.cap, p.max_read, p.max_hap, (uint32_t)k);
             const uint32_t stripe = (uint32_t)(cand.lanes * k);
@@ -1155,10 +753,10 @@ static int sweep_rescue(phmm_context *c, phmm_resident *rb)
         a.n_pairs = 0;
         a.n_pairs_dev = rb->rescue_count.p + qi;
         a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(p.max_hap);
-        a.no_early_exit = getenv("PHMM_NO_EARLY_EXIT") ? 1u : 0u;  // tests
+        a.no_early_exit = phmm_hook("PHMM_NO_EARLY_EXIT") ? 1u : 0u;  // tests
         a.ph2pr = c->ph2pr_f64.p;
         a.mm_table = c->mm_f64.p;
-        a.out_raw = rb->raw64.p;
+        a.out_raw = rb->out64_host ? static_cast<void *>(rb->out64_host) : static_cast<void *>(rb->raw64.p);
         HIP_TRY(phmm::launch_striped_f64(p.rows, rb->uniform_gcp, p.sh.waves, p.sh.lanes, a, rb->carry64.p + p.carry_at,
                                          p.max_hap + 1, p.teams, st));
     }
@@ -1341,7 +939,7 @@ static bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
     const bool cross = b->pair_read == nullptr;
     const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
     if (n < kChunkedMinPairs || b->n_reads == 0 || b->n_haps == 0) return false;
-    if (const char *e = getenv("PHMM_NO_CHUNKED_COMPUTE")) {  // tests
+    if (const char *e = phmm_hook("PHMM_NO_CHUNKED_COMPUTE")) {  // tests
         if (e[0] != '0') return false;
     }
     // Chunk sizes rise and fall (1 : 2 : 3 : 3 : 2 : 1): the first chunk's packing and the last chunk's host log10 are the
@@ -1349,7 +947,7 @@ static bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
     unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(2, n / kChunkTargetPairs + 2));
     std::vector<unsigned> weight(C);
     for (unsigned k = 0; k < C; ++k) weight[k] = std::min(k + 1, std::min(C - k, 3u));
-    if (const char *e = getenv("PHMM_CHUNK_WEIGHTS")) {  // tuning aid: relative chunk sizes, e.g. "1,2,3,2,1"
+    if (const char *e = phmm_hook("PHMM_CHUNK_WEIGHTS")) {  // tuning aid: relative chunk sizes, e.g. "1,2,3,2,1"
         std::vector<unsigned> w;
         for (const char *q = e; *q;) {
             char *end = nullptr;
@@ -1595,6 +1193,7 @@ static int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vect
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats)
 {
     if (!c || !b) return fail(PHMM_E_INVALID, "phmm_compute: null argument");
+    phmm_detail::HookScope hooks;
     const auto t0 = std::chrono::steady_clock::now();
     if (c->cpu) {
         if (!c->scratch) c->scratch = new phmm_resident();
@@ -2108,6 +1707,78 @@ int phmm_download_read_table(phmm_context *c, phmm_resident *rb, uint8_t *q, uin
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *raw, double *l10, phmm_stats *st)
 {
     return guarded("phmm_compute", [&] { return impl::phmm_compute(c, b, raw, l10, st); });
+}
+
+int phmm_compute_regions(phmm_context *c, const phmm_batch *t, const phmm_region *regions, uint32_t n_regions, float *raw, double *l10, phmm_stats *st)
+{
+    return guarded("phmm_compute_regions", [&] { return impl::phmm_compute_regions(c, t, regions, n_regions, raw, l10, st); });
+}
+int phmm_stage_create(phmm_context *c, const phmm_stage_caps *caps, phmm_stage **out)
+{
+    return guarded("phmm_stage_create", [&] { return impl::phmm_stage_create(c, caps, out); });
+}
+void phmm_stage_destroy(phmm_context *c, phmm_stage *st)
+{
+    (void)guarded("phmm_stage_destroy", [&] { impl::phmm_stage_destroy(c, st); return PHMM_OK; });
+}
+int phmm_stage_get_view(const phmm_stage *st, phmm_stage_view *view, phmm_stage_caps *caps)
+{
+    return guarded("phmm_stage_get_view", [&] { return impl::phmm_stage_get_view(st, view, caps); });
+}
+int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint32_t n_reads, uint32_t n_haps, const phmm_stage_params *prm)
+{
+    return guarded("phmm_stage_submit", [&] { return impl::phmm_stage_submit(c, st, n_regions, n_reads, n_haps, prm); });
+}
+int phmm_stage_wait(phmm_context *c, phmm_stage *st, phmm_stats *stats) { return guarded("phmm_stage_wait", [&] { return impl::phmm_stage_wait(c, st, stats); }); }
+uint64_t phmm_stage_pair_first(const phmm_stage *st, uint32_t region) { return impl::phmm_stage_pair_first(st, region); }
+int phmm_stage_log10(const phmm_stage *st, uint64_t first_pair, uint64_t n, double *out, float *raw, uint64_t *n_rescued)
+{
+    return guarded("phmm_stage_log10", [&] { return impl::phmm_stage_log10(st, first_pair, n, out, raw, n_rescued); });
+}
+
+// the binning alone (host only): lets the launch plan be checked on a machine without GPUs
+static int report_bins(const std::vector<Bin> &bins, int32_t *bin_rows, uint32_t *bin_first, uint32_t *bin_count, int max_bins)
+{
+    for (size_t i = 0; i < bins.size() && (int)i < max_bins; ++i) {
+        if (bin_rows) bin_rows[i] = bins[i].rows_per_lane;
+        if (bin_first) bin_first[i] = bins[i].first;
+        if (bin_count) bin_count[i] = bins[i].count;
+    }
+    return (int)bins.size();
+}
+int phmm_plan_bins(const phmm_batch *b, uint32_t *order, int32_t *bin_rows, uint32_t *bin_first, uint32_t *bin_count, int max_bins)
+{
+    int n_bins = 0;
+    const int rc = guarded("phmm_plan_bins", [&]() -> int {
+        if (!b || (b->pair_read == nullptr) != (b->pair_hap == nullptr)) return fail(PHMM_E_INVALID, "phmm_plan_bins: bad arguments");
+        const bool cross = b->pair_read == nullptr;
+        const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
+        if (n > 0xFFFFFFF0ull || (n && (!b->read_len || !b->hap_len))) return fail(PHMM_E_INVALID, "phmm_plan_bins: bad batch");
+        std::vector<uint32_t> pr(n), ph(n), ord(order ? 0 : n);
+        phmm_detail::BinScratch scratch;
+        std::vector<Bin> bins;
+        uint64_t cells = 0;
+        const int r = phmm_detail::bin_pairs(b, cross, n, 0, 0, pr.data(), ph.data(), order ? order : ord.data(), scratch, bins, &cells);
+        if (r != PHMM_OK) return r;
+        n_bins = report_bins(bins, bin_rows, bin_first, bin_count, max_bins);
+        return PHMM_OK;
+    });
+    return rc == PHMM_OK ? n_bins : -rc;
+}
+int phmm_plan_region_bins(const phmm_batch *t, const phmm_region *regions, uint32_t n_regions, uint32_t *slot_first, uint32_t *pair_first,
+                          int32_t *bin_rows, uint32_t *bin_first, uint32_t *bin_count, int max_bins)
+{
+    int n_bins = 0;
+    const int rc = guarded("phmm_plan_region_bins", [&]() -> int {
+        if (!t || (n_regions && !regions) || !slot_first || !pair_first) return fail(PHMM_E_INVALID, "phmm_plan_region_bins: null argument");
+        std::vector<Bin> bins;
+        uint64_t cells = 0, n_pairs = 0;
+        const int r = phmm_detail::bin_regions(regions, n_regions, t->read_len, t->n_reads, t->hap_len, t->n_haps, slot_first, pair_first, bins, &cells, &n_pairs);
+        if (r != PHMM_OK) return r;
+        n_bins = report_bins(bins, bin_rows, bin_first, bin_count, max_bins);
+        return PHMM_OK;
+    });
+    return rc == PHMM_OK ? n_bins : -rc;
 }
 
 int phmm_marginalize(phmm_context *c, const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count, const int32_t *old2new,

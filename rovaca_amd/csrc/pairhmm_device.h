@@ -1,4 +1,4 @@
-// pairhmm_device.h -- shared between the device code (pairhmm_kernels.hip) and the C-ABI host code (pairhmm_capi.cpp).
+// pairhmm_device.h -- shared between the device code (pairhmm_kernels.hip, pairhmm_setup.hip) and the C-ABI host code.
 #ifndef ROVACA_AMD_PAIRHMM_DEVICE_H_
 #define ROVACA_AMD_PAIRHMM_DEVICE_H_
 #include <hip/hip_runtime.h>
@@ -104,6 +104,38 @@ struct SetupArgs
     uint32_t *rescue_count;  // kRescueQueues counters, zeroed if non-null
 };
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s);
+// set-up of a region batch that arrived through pinned staging (phmm_stage): one launch, see pairhmm_setup.hip
+constexpr int kStageSetupThreads = 256;
+constexpr int kStageLdsBytes = 4096;  // sequence bytes a set-up workgroup parks in LDS at a time
+struct StageReadDesc  // written by the submitting thread behind the used part of the arena, one per read (32 bytes)
+{
+    uint32_t off, len;        // the read's bases in the arena
+    uint32_t qual_off;        // its raw base qualities in the arena
+    uint32_t slot_first;      // position in `order` of its first pair
+    uint32_t pair_first;      // id of its first pair (its region's first pair + row * n_haps)
+    uint32_t hap_first, n_haps;
+    uint32_t mapq;
+};
+struct StageHapDesc  // 16 bytes
+{
+    uint32_t off, len, plane_off, pad;
+};
+struct StageSetupArgs
+{
+    // the submission as it was copied from the stage: the byte arena and, behind its used part, the descriptors (HBM)
+    const uint8_t *arena;
+    const StageReadDesc *read_desc;
+    const StageHapDesc *hap_desc;
+    // what the sweep kernels index (HBM).  The read table keeps the arena's offsets: read_bases IS the arena, the prepared
+    // qualities / gap-opens / gap-continuations are parallel arrays indexed by the same offsets
+    uint8_t *read_qual, *read_gop, *read_gcp;
+    uint32_t *read_off, *read_len, *hap_len, *plane_off, *planes, *pair_read, *pair_hap, *order;
+    uint32_t n_reads, n_haps;
+    int32_t min_q, pcr_model;
+    uint8_t gap_open, gap_cont;
+    uint32_t *rescue_count;  // kRescueQueues counters, zeroed
+};
+hipError_t launch_stage_setup(const StageSetupArgs &a, hipStream_t s);
 // allele marginalisation (pairhmm_marginal.hip): device pointers; old [n_old][stride], out [n_new][evidence_count]
 hipError_t launch_marginalize(const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count, const int32_t *old2new,
                               uint32_t n_new, double *out, hipStream_t s);

@@ -1,0 +1,240 @@
+// pairhmm_engine.h -- internals shared by the translation units behind include/pairhmm_hip.h (pairhmm_capi.cpp: contexts, resident
+// batches, launches, multi-device handle; pairhmm_stage.cpp: region-descriptor batches through pinned staging; pairhmm_binning.cpp:
+// the length binning, host only).  Not part of the ABI.
+#ifndef ROVACA_AMD_PAIRHMM_ENGINE_H_
+#define ROVACA_AMD_PAIRHMM_ENGINE_H_
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/pairhmm_hip.h"
+#include "pairhmm_binning.h"
+#include "pairhmm_device.h"
+
+namespace phmm_detail
+{
+extern thread_local char g_err[512];           // text of the calling thread's last failure (phmm_last_error)
+int fail(int code, const char *fmt, ...);      // formats g_err, returns code
+}  // namespace phmm_detail
+using phmm_detail::fail;
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e__ = (expr);                                                                               \
+        if (e__ != hipSuccess) return fail(PHMM_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));        \
+    } while (0)
+
+template <typename T>
+struct DevBuf
+{
+    T *p = nullptr;
+    size_t n = 0;    // elements in use
+    size_t cap = 0;  // elements allocated (grow-only, so a context's scratch batch stops allocating after a few calls)
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    void reset()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = cap = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        if (count <= cap) {
+            n = count;
+            return hipSuccess;
+        }
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = cap = 0;
+        const size_t want = count + count / 4 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+        if (e != hipSuccess) return e;
+        cap = want;
+        n = count;
+        return hipSuccess;
+    }
+    hipError_t upload(const T *src, size_t count, hipStream_t s)
+    {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+};
+
+// a typed window into the resident batch's single input blob (not owned)
+template <typename T>
+struct DevView
+{
+    T *p = nullptr;
+    size_t n = 0;
+};
+
+// pinned host staging, grow-only
+struct HostBuf
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    HostBuf() = default;
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    ~HostBuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+};
+
+
+struct phmm_context
+{
+    // BASELINE config 1: a context made by phmm_create_cpu computes on the host (pairhmm_cpu.cpp) and owns no HIP object
+    bool cpu = false;
+    unsigned cpu_threads = 1;
+    bool cpu_simd = true;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf<float> ph2pr_f32, mm_f32;
+    DevBuf<double> ph2pr_f64, mm_f64;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the per-K launches of one pass are independent: they are spread over a few side streams so that the tail of one
+    // launch overlaps the head of the next (mixed-length batches have up to 17 launches per pass)
+    static constexpr int kSideStreams = 3;  // created
+    int n_side = 2;                         // used (PHMM_SIDE_STREAMS overrides: tuning; 2 and 3 measure the same, 0 loses 40 % on config 5)
+    hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
+    struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
+    // big one-shot batches are cut into chunks that alternate between two resident slots: chunk k + 1 is binned, packed and
+    // uploaded (on side[2]) while chunk k is swept, chunk k - 1 finalised on the host meanwhile
+    struct phmm_resident *chunk_slot[2] = {nullptr, nullptr};
+    hipEvent_t chunk_up[2] = {nullptr, nullptr}, chunk_done[2] = {nullptr, nullptr};
+    phmm_detail::BinScratch bin_scratch;       // host scratch of the length binning, kept between calls
+    std::vector<hipEvent_t> timing;            // event pool of phmm_sweep_timed
+    struct phmm_stage *region_stage = nullptr; // phmm_compute_regions: the stage host buffers are copied into (pairhmm_stage.cpp)
+    DevBuf<uint8_t> marg_dev;                  // phmm_marginalize: [old matrix][index map][result]
+    HostBuf marg_stage;
+};
+
+// Geometry of a striped launch.  lanes: 16 puts four pairs in a wave, 64 gives a whole wave to one pair (chosen when the
+// launch has so few pairs that four-per-wave would leave most of the chip idle and the reads are long enough to fill 64-lane
+// stripes).  waves: how many waves pipeline the stripes of the same pairs -- enough stripes to keep them busy, a haplotype
+// long enough for the pipeline lag (4 or 6 supersteps of 32 columns per wave), and only when the batch is small.
+struct TeamShape
+{
+    int lanes, waves;
+};
+static TeamShape pick_team_shape(uint32_t n_pairs, uint32_t max_read, uint32_t max_hap, uint32_t rows_per_lane)
+{
+    TeamShape sh{16, 1};
+    if ((n_pairs + 3) / 4 < 1024 && max_read > 64u * rows_per_lane) sh.lanes = 64;
+    // long reads take a wave each whatever the batch size: the zero-superstep shortcut works per wave, and four pairs in a
+    // wave are rarely all zero at the same columns (measured on 6 000 pairs of 2 000 x 2 400: fp32 4.7 -> 3.5 ms, fp64 15.7
+    // -> 12.9 ms; on 1 000 x 1 200 the fp64 re-run gains, the fp32 sweep does not)
+    if (max_read >= (rows_per_lane >= 8 ? 1536u : 768u)) sh.lanes = 64;
+    if (const char *f = phmm_hook("PHMM_FORCE_TEAM_LANES")) {  // tests
+        const int l = atoi(f);
+        if (l == 16 || l == 64) sh.lanes = l;
+    }
+    const uint32_t per_wave = 64u / (uint32_t)sh.lanes;
+    const uint32_t batches = (n_pairs + per_wave - 1) / per_wave;
+    // teams of several waves run the band kernel, whose stripes are kBandRows rows per lane tall whatever the one-wave shape is
+    const uint32_t stripes = (max_read + sh.lanes * phmm::kBandRows - 1) / (sh.lanes * phmm::kBandRows);
+    const uint32_t supersteps = (max_hap + (uint32_t)sh.lanes - 1 + 31) / 32;
+    const uint32_t lag = sh.lanes == 64 ? 6u : 4u;  // team_lag<G>() of the kernel
+    // (one pair per wave: since all-zero supersteps are skipped only one or two waves of a team have work at any time, and
+    // eight waves per pair measured slower than four on config 5)
+    if (sh.lanes == 16 && batches < 2048 && stripes >= 8 && supersteps >= lag * 8 + 12)
+        sh.waves = 8;
+    else if (batches < 4096 && stripes >= 4 && supersteps >= lag * 4 + 12)
+        sh.waves = 4;
+    if (const char *f = phmm_hook("PHMM_FORCE_TEAM_WAVES")) {  // tests: exercise every team width on small batches
+        const int w = atoi(f);
+        if ((w == 1 || w == 4 || w == 8) && supersteps >= lag * w + 12u) sh.waves = w;
+    }
+    return sh;
+}
+
+// a batch kept by a CPU context: deep copies of the tables (prepared: H3/H4 already applied when the batch asked for it)
+struct CpuBatch
+{
+    std::vector<uint8_t> bases, qual, ins, del, gcp, haps;
+    std::vector<uint32_t> roff, rlen, hoff, hlen, pr, ph;
+    std::vector<float> raw32;
+    std::vector<double> raw64;
+    std::vector<uint8_t> rescued;
+    phmm_batch view{};
+};
+
+struct phmm_resident
+{
+    CpuBatch *cpu = nullptr;
+    ~phmm_resident() { delete cpu; }
+    uint64_t n_pairs = 0, cells = 0;
+    uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
+    bool uniform_gcp = false, uniform_gop = false;
+    // inputs travel as ONE pinned staging buffer and ONE host-to-device copy per upload (a region-sized submission is
+    // latency-bound: fifteen small copies cost more than the sweep); the views below point into `blob`
+    HostBuf stage, out_stage;
+    DevBuf<uint8_t> blob;
+    DevView<uint8_t> read_bases, read_qual, hap_bases, read_mapq;
+    DevView<uint32_t> read_off, read_len, hap_off, hap_len, pair_read, pair_hap, order, plane_off, word_owner;
+    DevView<uint8_t> read_ins, read_del, read_gcp;  // prepared batches: inside `blob`; otherwise the two buffers below
+    DevBuf<uint8_t> prep_gop, prep_gcp;             // written by the set-up launch (device-side read preparation)
+    DevBuf<uint32_t> planes;
+    DevBuf<float> raw32;
+    DevBuf<double> raw64;
+    DevBuf<uint32_t> rescue_list;
+    DevView<uint32_t> rescue_count;  // inside raw32, behind the sums
+    // a batch that lives in a phmm_stage: the kernels write their sums into the stage's pinned host arrays instead of raw32 / raw64
+    float *out32_host = nullptr;
+    double *out64_host = nullptr;
+    bool queue_is_empty = false;     // the set-up launch has just zeroed rescue_count
+    DevBuf<float> carry32;
+    DevBuf<double> carry64;
+    std::vector<Bin> bins;
+    uint32_t last_rescued = 0;
+    double last_kernel_ms = 0.0;
+};
+
+
+// The entry points are implemented in this namespace with C++ linkage; the extern "C" wrappers at the end of pairhmm_capi.cpp
+// catch whatever a body may throw, so that nothing crosses the C boundary.
+namespace impl
+{
+// pairhmm_capi.cpp: one pass over a resident batch, enqueued on the context's stream set; the CPU backend's two steps
+int sweep_fp32(phmm_context *c, phmm_resident *rb);
+int sweep_rescue(phmm_context *c, phmm_resident *rb);
+int cpu_upload(phmm_context *c, const phmm_batch *b, phmm_resident *rb);
+int cpu_sweep(phmm_context *c, phmm_resident *rb);
+int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats);
+// pairhmm_stage.cpp
+int phmm_stage_create(phmm_context *c, const phmm_stage_caps *caps, phmm_stage **out);
+void phmm_stage_destroy(phmm_context *c, phmm_stage *st);
+int phmm_stage_get_view(const phmm_stage *st, phmm_stage_view *view, phmm_stage_caps *caps);
+int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint32_t n_reads, uint32_t n_haps, const phmm_stage_params *prm);
+int phmm_stage_wait(phmm_context *c, phmm_stage *st, phmm_stats *stats);
+uint64_t phmm_stage_pair_first(const phmm_stage *st, uint32_t region);
+int phmm_stage_log10(const phmm_stage *st, uint64_t first_pair, uint64_t n, double *out, float *out_raw_f32, uint64_t *n_rescued);
+int phmm_compute_regions(phmm_context *c, const phmm_batch *t, const phmm_region *regions, uint32_t n_regions, float *out_raw_f32,
+                         double *out_log10, phmm_stats *stats);
+}  // namespace impl
+#endif

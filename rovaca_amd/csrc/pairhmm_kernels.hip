@@ -103,44 +103,6 @@ template <> struct Num<double>
 };
 
 // ----------------------------------------------------------------------------------------------------
-// haplotype bit planes.  One thread per (haplotype, 32-column word).  Column j (1-based) is bit
-// 31 - ((j-1) & 31) of word (j-1) >> 5: MSB first, so that `v_add_co_u32 m, vcc, m, m` pops the next column.
-//   plane 0..3: read base A/C/G/T matches this column (hap base equal, or hap base N)
-//   plane 4   : read base N matches this column (hap base is any of ACGTN)
-//   plane 5   : read symbol outside ACGTN: never matches (all zero)
-// Words past the haplotype end are zero.
-// ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void hap_planes_word(const uint8_t *__restrict__ hap_bases, const uint32_t *__restrict__ hap_off,
-                                                const uint32_t *__restrict__ hap_len, const uint32_t *__restrict__ plane_off,
-                                                const uint32_t *__restrict__ word_owner, uint32_t n_words,
-                                                uint32_t *__restrict__ planes, uint32_t g)
-{
-    if (g >= n_words) return;
-    // word_owner[g] = haplotype that owns global word slot g; the slot index inside that haplotype follows
-    uint32_t h = word_owner[g];
-    uint32_t H = hap_len[h];
-    uint32_t W = planes_words(H);
-    uint32_t w = g - (plane_off[h] / kPlanes);  // plane_off is in words and counts kPlanes * W per haplotype
-    const uint8_t *hb = hap_bases + hap_off[h];
-    uint32_t bits[kPlanes] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t b = 0; b < 32; ++b) {
-        uint32_t j0 = w * 32 + b;
-        if (j0 < H) {
-            uint8_t c = hb[j0];
-            uint32_t bit = 0x80000000u >> b;
-            bool isN = c == 'N';
-            if (c == 'A' || isN) bits[0] |= bit;
-            if (c == 'C' || isN) bits[1] |= bit;
-            if (c == 'G' || isN) bits[2] |= bit;
-            if (c == 'T' || isN) bits[3] |= bit;
-            if (c == 'A' || c == 'C' || c == 'G' || c == 'T' || isN) bits[4] |= bit;
-        }
-    }
-    uint32_t *dst = planes + plane_off[h];
-    for (int c = 0; c < kPlanes; ++c) dst[c * W + w] = bits[c];
-}
-
-// ----------------------------------------------------------------------------------------------------
 // the systolic kernel
 // ----------------------------------------------------------------------------------------------------
 template <typename T, int K, bool UG>
@@ -1499,88 +1461,6 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
 }
 
 // ----------------------------------------------------------------------------------------------------
-// device-side read preparation: H3 quality modification and H4 PCR indel model, one workgroup
-// per read, one thread per base.  Integer work, exact.  Follows pairhmm_internal.cpp:434-439 and :65-159 / :195-229
-// including the quirks the host adapter documents (rovaca_amd/host/pairhmm_host_logic.cpp).
-// ----------------------------------------------------------------------------------------------------
-__device__ int32_t count_tiled_units_dev(const uint8_t *unit, int32_t ulen, const uint8_t *text, int32_t tlen, bool from_front)
-{
-    if (tlen == 0) return 0;
-    int32_t copies = 0;
-    const int32_t last = tlen - ulen;
-    if (from_front) {
-        for (int32_t at = 0; at <= last; at += ulen, ++copies) {
-            bool same = true;
-            for (int32_t i = 0; i < ulen; ++i) same = same && (text[at + i] == unit[i]);
-            if (!same) break;
-        }
-    }
-    else {
-        for (int32_t at = last; at >= 0; at -= ulen, ++copies) {
-            bool same = true;
-            for (int32_t i = 0; i < ulen; ++i) same = same && (text[at + i] == unit[i]);
-            if (!same) break;
-        }
-    }
-    return copies;
-}
-
-__device__ int32_t tandem_repeat_length_dev(const uint8_t *bases, int32_t len, int32_t offset)
-{
-    const int32_t prefix = offset + 1;
-    int32_t backward = 0;
-    for (int32_t unit = 1; unit <= 8 && unit <= prefix; ++unit) {
-        backward = count_tiled_units_dev(bases + prefix - unit, unit, bases, prefix, false);
-        if (backward > 1) break;
-    }
-    int32_t total = backward;
-    if (offset < len - 1) {
-        const int32_t suffix = len - prefix;
-        int32_t forward = 0, fw_unit = 1;
-        for (int32_t unit = 1; unit <= 8 && unit <= suffix; ++unit) {
-            forward = count_tiled_units_dev(bases + prefix, unit, bases + prefix, suffix, true);
-            if (forward > 1) {
-                fw_unit = unit;
-                break;
-            }
-        }
-        backward = count_tiled_units_dev(bases + prefix, fw_unit, bases, prefix, false);
-        total = backward + forward;
-    }
-    return total < 20 ? total : 20;
-}
-
-__constant__ uint8_t kPcrCap[4][21] = {
-    {255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255},
-    {40, 40, 39, 38, 37, 36, 34, 32, 28, 23, 17, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10},   // HOSTILE      adapter.h:13
-    {40, 40, 40, 39, 39, 39, 38, 38, 37, 37, 36, 35, 34, 33, 32, 30, 28, 26, 23, 20, 17},   // AGGRESSIVE   adapter.h:14
-    {40, 40, 40, 40, 39, 39, 39, 39, 39, 38, 38, 38, 37, 37, 37, 36, 36, 35, 34, 33, 33}};  // CONSERVATIVE adapter.h:15
-
-__device__ __forceinline__ void prep_one_read(const uint8_t *__restrict__ read_bases, uint8_t *__restrict__ read_qual,
-                                              uint8_t *__restrict__ read_gop, uint8_t *__restrict__ read_gcp,
-                                              const uint32_t *__restrict__ read_off, const uint32_t *__restrict__ read_len,
-                                              const uint8_t *__restrict__ read_mapq, int32_t min_q, int32_t pcr_model,
-                                              uint8_t gap_open, uint8_t gap_cont, uint32_t r)
-{
-    const uint32_t off = read_off[r], n = read_len[r];
-    const uint8_t mq = read_mapq[r];
-    const uint8_t *bases = read_bases + off;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        uint8_t q = read_qual[off + i];
-        q = q < mq ? q : mq;
-        q = (int32_t)q < min_q ? (uint8_t)6 : q;
-        read_qual[off + i] = q;
-        uint8_t g = gap_open;
-        if (pcr_model != 0 && i + 1 < n) {  // the last base keeps its gap-open
-            const uint8_t cap = kPcrCap[pcr_model][tandem_repeat_length_dev(bases, (int32_t)n, (int32_t)i)];
-            g = g < cap ? g : cap;
-        }
-        read_gop[off + i] = g;
-        read_gcp[off + i] = gap_cont;
-    }
-}
-
-// ----------------------------------------------------------------------------------------------------
 // launchers (one instantiation per rows-per-lane K)
 // ----------------------------------------------------------------------------------------------------
 // grid of a single-pass launch: with XCD-local ordering it is rounded up to whole rounds of 8 runs (the extra workgroups find no pair)
@@ -1704,29 +1584,6 @@ hipError_t launch_striped_f64(int rows_per_lane, bool uniform_gcp, int waves_per
     if (rows_per_lane == 5) return launch_team_w<double, 5, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
     if (rows_per_lane == 6) return launch_team_w<double, 6, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
     return hipErrorInvalidValue;
-}
-
-// One launch sets a batch up: workgroups [0, n_prep_reads) prepare one read each (H3 + H4, only for batches that carry a
-// phmm_read_prep), the rest build the haplotype bit planes, one thread per 32-column word; the rescue queue is emptied on
-// the way.  A region-sized call is a chain of dependent launches and copies, each worth 5-10 us: fewer links, lower latency.
-__global__ void __launch_bounds__(kSetupThreads) setup_kernel(SetupArgs s)
-{
-    if (blockIdx.x == 0 && threadIdx.x < kRescueQueues && s.rescue_count) s.rescue_count[threadIdx.x] = 0;
-    if (blockIdx.x < s.n_prep_reads) {
-        prep_one_read(s.read_bases, s.read_qual, s.read_gop, s.read_gcp, s.read_off, s.read_len, s.read_mapq, s.min_q, s.pcr_model,
-                      s.gap_open, s.gap_cont, blockIdx.x);
-        return;
-    }
-    hap_planes_word(s.hap_bases, s.hap_off, s.hap_len, s.plane_off, s.word_owner, s.n_words, s.planes,
-                    (blockIdx.x - s.n_prep_reads) * kSetupThreads + threadIdx.x);
-}
-
-hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
-{
-    const uint32_t blocks = a.n_prep_reads + (a.n_words + kSetupThreads - 1) / kSetupThreads;
-    if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(setup_kernel, dim3(blocks), dim3(kSetupThreads), 0, s, a);
-    return hipGetLastError();
 }
 
 }  // namespace phmm

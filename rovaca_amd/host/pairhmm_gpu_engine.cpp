@@ -16,7 +16,11 @@
 #include <mutex>
 #include <thread>
 
+#include <climits>
+#include <linux/futex.h>
 #include <pthread.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/pairhmm_hip.h"
@@ -66,32 +70,80 @@ thread_local ThreadContext t_ctx;
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Cross-region batching.  The caller evaluates one region per worker thread, synchronously
-// (haplotypecaller_engine.cpp:119-285); a region is 1e7-1e8 cells, i.e. tens of microseconds of MI355X time against a
-// fixed per-submission cost.  Workers therefore hand their flattened region to one dispatcher thread per device and
-// block on it; the dispatcher merges everything that queued up while the previous submission was on the device into ONE
-// phmm_batch (tables concatenated, pair indices rebased), runs it, and hands each worker its slice.  No timer: the batch
-// is whatever arrived during the last device round trip, so a single caller pays one thread hop and 30-128 callers are
-// coalesced automatically.
+// (haplotypecaller_engine.cpp:119-285); a region is 1e7-1e8 cells, i.e. a few microseconds of MI355X time against a fixed
+// per-submission cost of tens.  Workers therefore share STAGES: blocks of pinned host memory owned by the engine and laid out
+// as the device reads them (include/pairhmm_hip.h, phmm_stage).  A worker reserves ranges of the stage that is currently
+// filling (a mutex-guarded bump of six cursors), decodes its reads and copies its haplotypes STRAIGHT into the pinned tables
+// -- the only copy the bytes ever get on the host -- and commits.  Dispatcher threads (a few per device) take whatever has
+// gathered in the open stage as soon as they are free, make ONE asynchronous submission of it (region descriptors: the device
+// spells out the cross products, prepares the reads and builds the haplotype planes in one set-up launch; the kernels write the
+// sums back into the stage), wait for it and wake the stage's workers, each of which converts and post-processes its own
+// region from the pinned results.  The dispatcher touches O(reads + haplotypes) descriptors, never the bytes and never the
+// pairs.  No timer: a batch is whatever arrived while the dispatchers were busy, so a single caller pays one hand-off and
+// 30-128 callers are coalesced automatically.
 // ---------------------------------------------------------------------------------------------------------------------
-struct RegionJob
+// Where the adapter's host time goes (always on: a handful of clock reads per region and per submission).  Nanoseconds, summed over
+// threads; read with gpu_pairhmm_profile (tools/adapter_bench.cpp prints them, profiles/ keeps a run).
+enum ProfileSlot {
+    kProfReserve, kProfFill, kProfWaitResults, kProfConvert, kProfPostprocess,              // workers
+    kProfDispIdle, kProfDispCommitSpin, kProfDispSubmit, kProfDispDeviceWait, kProfDispWake,  // dispatchers
+    kProfSlots
+};
+std::atomic<uint64_t> g_prof[kProfSlots];
+struct ProfClock
 {
-    // inputs (owned by the submitting worker, alive until done)
-    const uint8_t *bases, *quals, *mapq, *hap_bases;  // quals are RAW: H3/H4 run on the device (phmm_read_prep)
-    const uint32_t *read_off, *read_len, *hap_off, *hap_len;
-    uint32_t n_reads, n_haps;
-    size_t read_bytes, hap_bytes;
-    int32_t min_q, pcr_model;
-    double *out;  // [read][hap]
-    // completion: `status` (and `error`, when it is a failure) are written before `done` is released
-    std::atomic<bool> done{false};
-    int status = PHMM_OK;
-    char error[256] = "";  // phmm_last_error() is thread-local to the dispatcher: the text travels with the job
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(ProfileSlot slot)
+    {
+        const auto n = std::chrono::steady_clock::now();
+        g_prof[slot].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(), std::memory_order_relaxed);
+        t = n;
+    }
 };
 
-// How long a thread polls before it sleeps on a condition variable (ROVACA_AMD_PAIRHMM_SPIN_US, default 0 = never).
-// Polling saves the futex wake and the core's idle-state exit on each hand-off, but measured on the GPU box (CPU time capped
-// per job) 30 workers fell from 74 000 to 59 000 regions/s with a 300 us budget and 128 workers to a third: the pollers eat
-// the cycles the dispatchers need.  Worth trying only where worker threads have cores to themselves.
+static long futex_call(std::atomic<uint32_t> *addr, int op, uint32_t val)
+{
+    return syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), op, val, nullptr, nullptr, 0);
+}
+
+// capacity of one stage: sixty regions of the usual size (48 reads x 9 haplotypes of 150 / 300 bases are 17 KB and 432 pairs), or one
+// very deep one; what does not fit an EMPTY stage takes the direct path (the worker's own context).  2.3 MB of pinned memory and
+// 3.5 MB of HBM each.  All stages are made at start-up (ROVACA_AMD_PAIRHMM_STAGES, default 32 per device: workers that keep several
+// regions in flight hold finished stages until they collect them); the pool grows up to kStagesMax when they run out, which costs
+// the worker that hits it a few milliseconds of allocation.
+constexpr phmm_stage_caps kStageCaps{64, 4096, 1024, 1u << 20, 64u * 1024u};
+constexpr int kStagesMax = 96;
+static int stages_at_start()
+{
+    const char *e = getenv("ROVACA_AMD_PAIRHMM_STAGES");
+    return std::max(2, std::min(kStagesMax, e ? atoi(e) : 32));
+}
+
+struct StageSlot
+{
+    phmm_stage *st = nullptr;
+    phmm_stage_view v{};
+    // fill cursors: written under the batcher's mutex while this is the open stage, frozen once a dispatcher has taken it
+    uint32_t n_regions = 0, n_reads = 0, n_haps = 0, bytes = 0, n_pairs = 0;
+    int32_t min_q = 0, pcr_model = 0;
+    std::atomic<uint32_t> committed{0};  // regions whose bytes are in place
+    std::atomic<uint32_t> state{0};      // futex word: 0 filling / on the device, 1 results in the stage, 2 failed
+    std::atomic<uint32_t> waiters{0};    // workers asleep on `state`
+    std::atomic<uint32_t> readers{0};    // regions not yet collected; the last one recycles the stage
+    int status = PHMM_OK;
+    char error[256] = "";  // phmm_last_error() is thread-local to the dispatcher: the text travels with the stage
+};
+
+struct Reservation
+{
+    StageSlot *slot = nullptr;
+    uint32_t region = 0, read_first = 0, hap_first = 0, byte_first = 0;
+};
+
+// How long a thread polls before it sleeps (ROVACA_AMD_PAIRHMM_SPIN_US, default 0 = never).  Polling saves the futex wake and
+// the core's idle-state exit on each hand-off, but measured on the GPU box (CPU time capped per job) 30 workers fell from
+// 74 000 to 59 000 regions/s with a 300 us budget and 128 workers to a third: the pollers eat the cycles the dispatchers need.
+// Worth trying only where worker threads have cores to themselves.
 static int spin_budget_us()
 {
     static const int us = [] {
@@ -119,169 +171,166 @@ static bool spin_until(Pred ready)
 class RegionBatcher
 {
 public:
-    explicit RegionBatcher(int device) : device_(device), worker_([this] { run(); }) {}
-    ~RegionBatcher()
+    RegionBatcher(int device, int n_dispatchers) : device_(device)
     {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        worker_.join();
+        if (phmm_create(device_, nullptr, &owner_) != PHMM_OK) die("cannot create a device context");
+        for (int i = 0, n = stages_at_start(); i < n; ++i) free_.push_back(new_slot());
+        for (int i = 0; i < n_dispatchers; ++i) threads_.emplace_back([this] { run(); });
     }
-    // the job (and everything it points at) must stay alive until wait() has returned
-    void submit(RegionJob &job)
+    // (never destroyed: the dispatcher threads would otherwise call into HIP during static teardown)
+
+    // A place for one region in the stage that is filling.  false: the region does not fit even an empty stage, or every stage
+    // is taken and the pool is at its limit -- the caller evaluates it on its own context instead (never blocks on other workers:
+    // a worker that keeps several regions in flight may hold the very stages it would be waiting for).
+    bool reserve(uint32_t n_reads, uint32_t n_haps, uint32_t bytes, int32_t min_q, int32_t pcr_model, Reservation &rv)
     {
+        const uint64_t n_pairs = (uint64_t)n_reads * n_haps;
+        if (n_reads > kStageCaps.max_reads || n_haps > kStageCaps.max_haps || bytes > kStageCaps.max_bytes || n_pairs > kStageCaps.max_pairs)
+            return false;
+        bool wake = false;
         {
-            std::lock_guard<std::mutex> lk(mu_);
-            queue_.push_back(&job);
-            ++pending_;
-        }
-        if (dispatcher_sleeps_.load(std::memory_order_acquire)) cv_.notify_one();
-    }
-    int wait(RegionJob &job)
-    {
-        if (!spin_until([&] { return job.done.load(std::memory_order_acquire); })) {
             std::unique_lock<std::mutex> lk(mu_);
-            ++sleepers_;
-            done_cv_.wait(lk, [&] { return job.done.load(std::memory_order_acquire); });
-            --sleepers_;
+            for (;;) {
+                if (!open_) {
+                    if (free_.empty()) {
+                        if (n_slots_ >= kStagesMax) return false;
+                        ++n_slots_;  // counted before the lock is dropped: the pool never overshoots
+                        lk.unlock();
+                        StageSlot *fresh = new_slot(false);
+                        lk.lock();
+                        free_.push_back(fresh);
+                        continue;
+                    }
+                    open_ = free_.back();
+                    free_.pop_back();
+                    open_->min_q = min_q;
+                    open_->pcr_model = pcr_model;
+                }
+                StageSlot &s = *open_;
+                const bool fits = s.n_regions < kStageCaps.max_regions && s.n_reads + n_reads <= kStageCaps.max_reads &&
+                                  s.n_haps + n_haps <= kStageCaps.max_haps && s.bytes + bytes <= kStageCaps.max_bytes &&
+                                  s.n_pairs + n_pairs <= kStageCaps.max_pairs;
+                // one device batch per distinct (threshold, PCR model); in practice they are process-wide constants
+                if (fits && s.min_q == min_q && s.pcr_model == pcr_model) break;
+                closed_.push_back(open_);  // full: a dispatcher takes it as it is
+                open_ = nullptr;
+                wake = true;
+            }
+            StageSlot &s = *open_;
+            rv.slot = &s;
+            rv.region = s.n_regions++;
+            rv.read_first = s.n_reads;
+            rv.hap_first = s.n_haps;
+            rv.byte_first = s.bytes;
+            s.n_reads += n_reads;
+            s.n_haps += n_haps;
+            s.bytes += bytes;
+            s.n_pairs += (uint32_t)n_pairs;
+            s.readers.fetch_add(1, std::memory_order_relaxed);
+            s.v.regions[rv.region] = phmm_region{rv.read_first, n_reads, rv.hap_first, n_haps};
+            wake = wake || idle_ != 0;
         }
-        return job.status;
+        if (wake) cv_.notify_one();  // the dispatcher wakes up while this worker is still writing its bytes
+        return true;
     }
-    int submit_and_wait(RegionJob &job)
+    static void commit(const Reservation &rv) { rv.slot->committed.fetch_add(1, std::memory_order_release); }
+    // blocks until the stage's results are in; returns the submission's status
+    static int wait(StageSlot &s)
     {
-        submit(job);
-        return wait(job);
+        if (!spin_until([&] { return s.state.load(std::memory_order_acquire) != 0; })) {
+            s.waiters.fetch_add(1);
+            while (s.state.load() == 0) futex_call(&s.state, FUTEX_WAIT_PRIVATE, 0);
+            s.waiters.fetch_sub(1);
+        }
+        return s.status;
+    }
+    // a region's results have been read (or are not wanted): the last one hands the stage back
+    void release(StageSlot &s)
+    {
+        if (s.readers.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+        s.n_regions = s.n_reads = s.n_haps = s.bytes = s.n_pairs = 0;
+        s.committed.store(0, std::memory_order_relaxed);
+        s.state.store(0, std::memory_order_release);
+        std::lock_guard<std::mutex> lk(mu_);
+        free_.push_back(&s);
     }
     std::atomic<uint64_t> regions{0}, submissions{0};
 
 private:
+    [[noreturn]] static void die(const char *what)
+    {
+        // the reference's convention for an unrecoverable engine failure: log, exit (pairhmm_engine.cpp:32-35)
+        fprintf(stderr, "[rovaca_amd] pairhmm: %s: %s\n", what, phmm_last_error());
+        exit(EXIT_FAILURE);
+    }
+    StageSlot *new_slot(bool count = true)
+    {
+        StageSlot *s = new StageSlot();
+        if (phmm_stage_create(owner_, &kStageCaps, &s->st) != PHMM_OK || phmm_stage_get_view(s->st, &s->v, nullptr) != PHMM_OK)
+            die("cannot create a pinned stage");
+        if (count) ++n_slots_;
+        return s;
+    }
     void run()
     {
         // named like the reference's own threads (haplotypecaller_engine.cpp:120) so that perf / top -H attribute the time
         pthread_setname_np(pthread_self(), "phmm-gpu-disp");
         phmm_context *ctx = nullptr;
-        if (phmm_create(device_, nullptr, &ctx) != PHMM_OK) {
-            fprintf(stderr, "[rovaca_amd] pairhmm: cannot create a device context: %s\n", phmm_last_error());
-            exit(EXIT_FAILURE);
-        }
-        std::vector<RegionJob *> taken, jobs;
-        std::vector<uint8_t> bases, quals, mapq, haps;
-        std::vector<uint32_t> roff, rlen, hoff, hlen, pr, ph;
-        std::vector<double> out;
+        if (phmm_create(device_, nullptr, &ctx) != PHMM_OK) die("cannot create a device context");
+        ProfClock clk;
         for (;;) {
-            if (!spin_until([&] { return pending_.load(std::memory_order_acquire) != 0; })) {
-                std::unique_lock<std::mutex> lk(mu_);
-                dispatcher_sleeps_.store(true, std::memory_order_release);
-                cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
-                dispatcher_sleeps_.store(false, std::memory_order_release);
-            }
+            StageSlot *s = nullptr;
             {
-                std::lock_guard<std::mutex> lk(mu_);
-                if (stop_ && queue_.empty()) break;
-                taken.assign(queue_.begin(), queue_.end());
-                queue_.clear();
-                pending_.store(0, std::memory_order_release);
+                std::unique_lock<std::mutex> lk(mu_);
+                ++idle_;
+                cv_.wait(lk, [&] { return !closed_.empty() || (open_ && open_->n_regions != 0); });
+                --idle_;
+                if (!closed_.empty()) {
+                    s = closed_.front();
+                    closed_.pop_front();
+                }
+                else {
+                    s = open_;
+                    open_ = nullptr;  // the next worker opens a fresh stage
+                }
+                if (idle_ != 0 && (!closed_.empty() || (open_ && open_->n_regions != 0))) cv_.notify_one();
             }
-            if (taken.empty()) continue;
-            while (!taken.empty()) {
-                // one device batch per distinct (threshold, PCR model); in practice they are process-wide constants
-                jobs.clear();
-                const int32_t mq = taken.front()->min_q, pm = taken.front()->pcr_model;
-                for (auto it = taken.begin(); it != taken.end();) {
-                    if ((*it)->min_q == mq && (*it)->pcr_model == pm) {
-                        jobs.push_back(*it);
-                        it = taken.erase(it);
-                    }
-                    else {
-                        ++it;
-                    }
-                }
-                // merge: concatenate the tables, rebase the indices, spell the cross products out as one pair list
-                bases.clear();
-                quals.clear();
-                mapq.clear();
-                haps.clear();
-                roff.clear();
-                rlen.clear();
-                hoff.clear();
-                hlen.clear();
-                pr.clear();
-                ph.clear();
-                for (RegionJob *j : jobs) {
-                    const uint32_t r0 = (uint32_t)rlen.size(), h0 = (uint32_t)hlen.size();
-                    const uint32_t rb = (uint32_t)bases.size(), hb = (uint32_t)haps.size();
-                    bases.insert(bases.end(), j->bases, j->bases + j->read_bytes);
-                    quals.insert(quals.end(), j->quals, j->quals + j->read_bytes);
-                    mapq.insert(mapq.end(), j->mapq, j->mapq + j->n_reads);
-                    haps.insert(haps.end(), j->hap_bases, j->hap_bases + j->hap_bytes);
-                    for (uint32_t r = 0; r < j->n_reads; ++r) {
-                        roff.push_back(rb + j->read_off[r]);
-                        rlen.push_back(j->read_len[r]);
-                    }
-                    for (uint32_t h = 0; h < j->n_haps; ++h) {
-                        hoff.push_back(hb + j->hap_off[h]);
-                        hlen.push_back(j->hap_len[h]);
-                    }
-                    for (uint32_t r = 0; r < j->n_reads; ++r)
-                        for (uint32_t h = 0; h < j->n_haps; ++h) {
-                            pr.push_back(r0 + r);
-                            ph.push_back(h0 + h);
-                        }
-                }
-                phmm_read_prep prep{mapq.data(), mq, pm, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
-                phmm_batch b{};
-                b.n_reads = (uint32_t)rlen.size();
-                b.n_haps = (uint32_t)hlen.size();
-                b.n_pairs = pr.size();
-                b.read_bases = bases.data();
-                b.read_qual = quals.data();
-                b.read_off = roff.data();
-                b.read_len = rlen.data();
-                b.hap_bases = haps.data();
-                b.hap_off = hoff.data();
-                b.hap_len = hlen.data();
-                b.pair_read = pr.data();
-                b.pair_hap = ph.data();
-                b.prep = &prep;
-                out.resize(pr.size());
-                const int rc = phmm_compute(ctx, &b, nullptr, out.data(), nullptr);
-                const char *why = rc == PHMM_OK ? "" : phmm_last_error();
-                regions += jobs.size();
-                submissions += 1;
-                size_t at = 0;
-                for (RegionJob *j : jobs) {
-                    const size_t n = (size_t)j->n_reads * j->n_haps;
-                    if (rc == PHMM_OK) memcpy(j->out, out.data() + at, n * sizeof(double));
-                    at += n;
-                    j->status = rc;
-                    if (rc != PHMM_OK) snprintf(j->error, sizeof(j->error), "%s", why);
-                    j->done.store(true, std::memory_order_release);  // the job may be gone from here on
-                }
-                bool wake;
-                {
-                    std::lock_guard<std::mutex> lk(mu_);  // a worker that is about to sleep either sees `done` or is counted
-                    wake = sleepers_ != 0;
-                }
-                if (wake) done_cv_.notify_all();
+            clk.lap(kProfDispIdle);
+            // the regions counted in are being written right now: a few microseconds each
+            for (int spins = 0; s->committed.load(std::memory_order_acquire) != s->n_regions; ++spins) {
+                if (spins < 256)
+                    __builtin_ia32_pause();
+                else
+                    std::this_thread::yield();  // (a writer that lost its core: let it run)
             }
+            clk.lap(kProfDispCommitSpin);
+            const phmm_stage_params prm{s->min_q, s->pcr_model, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
+            int rc = phmm_stage_submit(ctx, s->st, s->n_regions, s->n_reads, s->n_haps, &prm);
+            clk.lap(kProfDispSubmit);
+            if (rc == PHMM_OK) rc = phmm_stage_wait(ctx, s->st, nullptr);
+            clk.lap(kProfDispDeviceWait);
+            s->status = rc;
+            if (rc != PHMM_OK) snprintf(s->error, sizeof(s->error), "%s", phmm_last_error());
+            regions += s->n_regions;
+            submissions += 1;
+            s->state.store(rc == PHMM_OK ? 1u : 2u);  // the stage may be recycled by its last reader from here on
+            if (s->waiters.load() != 0) futex_call(&s->state, FUTEX_WAKE_PRIVATE, INT32_MAX);
+            clk.lap(kProfDispWake);
         }
-        phmm_destroy(ctx);
     }
 
     int device_;
+    phmm_context *owner_ = nullptr;  // the context the stages are created on (their device buffers belong to its device)
     std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
-    std::deque<RegionJob *> queue_;
-    std::atomic<uint32_t> pending_{0};
-    std::atomic<bool> dispatcher_sleeps_{false};
-    int sleepers_ = 0;  // workers blocked on done_cv_ (guarded by mu_)
-    bool stop_ = false;
-    std::thread worker_;
+    std::condition_variable cv_;
+    StageSlot *open_ = nullptr;       // the stage that is filling
+    std::deque<StageSlot *> closed_;  // full stages waiting for a dispatcher
+    std::vector<StageSlot *> free_;
+    int n_slots_ = 0, idle_ = 0;      // guarded by mu_
+    std::vector<std::thread> threads_;
 };
 
-// one per device in use; intentionally never destroyed (their threads would otherwise call into HIP during static teardown)
+// one per device in use; intentionally never destroyed
 std::vector<RegionBatcher *> g_batchers;
 std::atomic<bool> g_batching{false};
 std::atomic<uint32_t> g_next_batcher{0};
@@ -296,16 +345,15 @@ bool init_pairhmm_ptr_gpu(int device_id)
     const char *env = getenv("ROVACA_AMD_PAIRHMM_BATCHING");
     const bool batching = !(env && env[0] == '0');
     if (batching && g_batchers.empty()) {
-        // a few dispatchers per device: while one batch is on the device the next one is being merged and uploaded
+        // a few dispatchers per device: while one submission is on the device the next stage is filling and a third is being
+        // converted by its workers
         const char *nd = getenv("ROVACA_AMD_PAIRHMM_DISPATCHERS");
         const int per_device = std::max(1, std::min(8, nd ? atoi(nd) : 3));
-        for (int k = 0; k < per_device; ++k) {
-            if (device_id >= 0) {
-                g_batchers.push_back(new RegionBatcher(device_id));
-            }
-            else {
-                for (int d = 0; d < n; ++d) g_batchers.push_back(new RegionBatcher(d));
-            }
+        if (device_id >= 0) {
+            g_batchers.push_back(new RegionBatcher(device_id, per_device));
+        }
+        else {
+            for (int d = 0; d < n; ++d) g_batchers.push_back(new RegionBatcher(d, per_device));
         }
     }
     g_batching.store(batching);
@@ -327,37 +375,57 @@ void gpu_pairhmm_batching_stats(uint64_t *regions, uint64_t *submissions)
 
 bool gpu_pairhmm_active() { return g_active.load(); }
 
-// A region between call_gpu_pairhmm_begin and call_gpu_pairhmm_finish: the flattened tables the dispatcher reads, the
-// [read][hap] result it writes, and the job record.  Heap-allocated once per region; nothing in it refers to the caller's
-// vectors, so the caller may go on to its next region while this one is on the device.
+int gpu_pairhmm_profile(double *seconds, const char **names, int cap)
+{
+    static const char *const kNames[kProfSlots] = {"worker: reserve a place in the open stage", "worker: decode reads + copy haplotypes into the stage",
+                                                   "worker: blocked until the stage's results are in", "worker: log10 of the region's sums",
+                                                   "worker: normalise, filter, transpose (H8)", "dispatcher: idle (no region waiting)",
+                                                   "dispatcher: waiting for regions to be committed", "dispatcher: phmm_stage_submit (bin + 3 launches)",
+                                                   "dispatcher: phmm_stage_wait (device)", "dispatcher: waking the stage's workers"};
+    for (int i = 0; i < kProfSlots && i < cap; ++i) {
+        if (seconds) seconds[i] = (double)g_prof[i].load() * 1e-9;
+        if (names) names[i] = kNames[i];
+    }
+    return kProfSlots;
+}
+
+// A region between call_gpu_pairhmm_begin and call_gpu_pairhmm_finish.  Batched: its place in a stage (the bytes live in the
+// stage's pinned tables, the results will appear there too).  Direct (batching off, or a region too large for a stage): evaluated
+// inside begin on the calling thread's own context; the flattened tables and the [read][hap] result are kept here.  Nothing in it
+// refers to the caller's vectors, so the caller may go on to its next region while this one is on the device.
 struct PairhmmTicket::State
 {
-    std::vector<uint32_t> read_off, read_len, hap_off, hap_len;
-    std::vector<int32_t> seq_len;
-    std::vector<uint8_t> bases, quals, mapq, hap_bases;
-    std::vector<double> likelihood;  // [read][hap]
     size_t reads_num = 0, haplotypes_num = 0;
-    RegionJob job{};
-    RegionBatcher *batcher = nullptr;  // null: evaluated inside begin (batching off), `rc` / `why` hold the outcome
+    RegionBatcher *batcher = nullptr;  // non-null while the region holds a place in a stage
+    Reservation rv;
+    // direct path only
+    std::vector<int32_t> seq_len;
+    std::vector<double> likelihood;  // [read][hap]
     int rc = PHMM_OK;
     char why[256] = "";
+    void abandon()  // the region is not wanted any more: wait until the device is done with the stage, give the place back
+    {
+        if (!batcher) return;
+        (void)RegionBatcher::wait(*rv.slot);
+        batcher->release(*rv.slot);
+        batcher = nullptr;
+    }
 };
 PairhmmTicket::PairhmmTicket() = default;
 PairhmmTicket::PairhmmTicket(PairhmmTicket &&) noexcept = default;
 PairhmmTicket &PairhmmTicket::operator=(PairhmmTicket &&o) noexcept
 {
-    // assigning over a ticket that is still in flight (a look-ahead loop that skipped finish for the previous region): the
-    // dispatcher reads its tables and writes its result buffer until the job is done, so wait first -- as the destructor does
+    // assigning over a ticket that is still in flight (a look-ahead loop that skipped finish for the previous region): its stage
+    // cannot be recycled under the device, so wait first -- as the destructor does
     if (this != &o) {
-        if (st_ && st_->batcher) st_->batcher->wait(st_->job);
+        if (st_) st_->abandon();
         st_ = std::move(o.st_);
     }
     return *this;
 }
 PairhmmTicket::~PairhmmTicket()
 {
-    // a ticket dropped without finish: the dispatcher may still be writing into it
-    if (st_ && st_->batcher) st_->batcher->wait(st_->job);
+    if (st_) st_->abandon();  // a ticket dropped without finish
 }
 
 PairhmmTicket call_gpu_pairhmm_begin(const HaplotypeVector &hs, const ReadVector &rs, int32_t min_quality_threshold, PcrIndelModel pcr_option)
@@ -368,87 +436,102 @@ PairhmmTicket call_gpu_pairhmm_begin(const HaplotypeVector &hs, const ReadVector
     PairhmmTicket::State &st = *t.st_;
     const size_t reads_num = st.reads_num = rs.size();
     const size_t haplotypes_num = st.haplotypes_num = hs.size();
+    const int model = static_cast<int>(pcr_option);
 
-    // ---- flatten: read table ----
-    st.read_off.resize(reads_num);
-    st.read_len.resize(reads_num);
-    st.seq_len.resize(reads_num);
-    size_t total = 0;
+    // sizes.  Every read is decoded in place by ReadRecord::decode_base, which writes a Bases record -- a 4-byte count, then the
+    // bases (genotype_struct.h:11-15) -- so each read gets a 4-byte-aligned slot: count, bases, raw qualities.
+    size_t bytes = 4;
     int32_t max_len = 0;
     for (size_t i = 0; i < reads_num; ++i) {
-        st.seq_len[i] = rs[i]->seq_length();
-        st.read_off[i] = (uint32_t)total;
-        st.read_len[i] = (uint32_t)st.seq_len[i];
-        total += (size_t)st.seq_len[i];
-        max_len = std::max(max_len, st.seq_len[i]);
+        const int32_t n = rs[i]->seq_length();
+        bytes += ((2 * (size_t)n + 3) & ~size_t(3)) + 4;
+        max_len = std::max(max_len, n);
     }
-    // H3 (quality modification) and H4 (PCR indel model) run on the device (phmm_read_prep); the host only gathers bytes
-    st.bases.resize(total);
-    st.quals.resize(total);
-    st.mapq.resize(reads_num);
+    for (size_t j = 0; j < haplotypes_num; ++j) bytes += hs[j]->get_display_string()->num;
+
+    Reservation rv;
+    RegionBatcher *batcher = nullptr;
+    ProfClock clk;
+    if (g_batching.load() && !g_batchers.empty() && bytes < UINT32_MAX && reads_num < UINT32_MAX && haplotypes_num < UINT32_MAX) {
+        batcher = g_batchers[g_next_batcher.fetch_add(1, std::memory_order_relaxed) % g_batchers.size()];
+        if (!batcher->reserve((uint32_t)reads_num, (uint32_t)haplotypes_num, (uint32_t)bytes, min_quality_threshold, model, rv)) batcher = nullptr;
+    }
+    if (batcher) {
+        clk.lap(kProfReserve);
+        // ---- flatten straight into the stage's pinned arena: the one copy these bytes get on the host.  H3 (quality
+        // modification) and H4 (PCR indel model) run on the device; the host only gathers bytes ----
+        const phmm_stage_view &v = rv.slot->v;
+        uint32_t at = (rv.byte_first + 3u) & ~3u;
+        for (size_t i = 0; i < reads_num; ++i) {
+            pReadRecord read = rs[i];
+            const uint32_t n = (uint32_t)read->seq_length(), off = at + 4;
+            read->decode_base(reinterpret_cast<pBases>(v.bytes + at));  // count at `at`, bases at `off`
+            memcpy(v.bytes + off + n, read->qual(), n);
+            const uint32_t r = rv.read_first + (uint32_t)i;
+            v.read_off[r] = off;
+            v.read_qual_off[r] = off + n;
+            v.read_len[r] = n;
+            v.read_mapq[r] = read->mapping_quality();
+            at = (off + 2 * n + 3u) & ~3u;
+        }
+        for (size_t j = 0; j < haplotypes_num; ++j) {
+            const pBases hb = hs[j]->get_display_string();
+            memcpy(v.bytes + at, hb->data, hb->num);
+            v.hap_off[rv.hap_first + j] = at;
+            v.hap_len[rv.hap_first + j] = hb->num;
+            at += hb->num;
+        }
+        RegionBatcher::commit(rv);
+        clk.lap(kProfFill);
+        st.batcher = batcher;
+        st.rv = rv;
+        return t;
+    }
+
+    // ---- direct path: flatten into the ticket, evaluate on this thread's own context ----
+    std::vector<uint32_t> read_off(reads_num), read_len(reads_num), hap_off(haplotypes_num), hap_len(haplotypes_num);
+    st.seq_len.resize(reads_num);
+    size_t total = 0;
+    for (size_t i = 0; i < reads_num; ++i) {
+        st.seq_len[i] = rs[i]->seq_length();
+        read_off[i] = (uint32_t)total;
+        read_len[i] = (uint32_t)st.seq_len[i];
+        total += (size_t)st.seq_len[i];
+    }
+    std::vector<uint8_t> bases(total), quals(total), mapq(reads_num);
     std::vector<uint8_t> tmp(sizeof(Bases) + (size_t)max_len + 1);
     pBases read_bases = reinterpret_cast<pBases>(tmp.data());
     for (size_t i = 0; i < reads_num; ++i) {
         pReadRecord read = rs[i];
-        const uint32_t n = st.read_len[i], o = st.read_off[i];
         read->decode_base(read_bases);
-        memcpy(st.bases.data() + o, read_bases->data, n);
-        memcpy(st.quals.data() + o, read->qual(), n);
-        st.mapq[i] = read->mapping_quality();
+        memcpy(bases.data() + read_off[i], read_bases->data, read_len[i]);
+        memcpy(quals.data() + read_off[i], read->qual(), read_len[i]);
+        mapq[i] = read->mapping_quality();
     }
-    // ---- flatten: haplotype table ----
-    st.hap_off.resize(haplotypes_num);
-    st.hap_len.resize(haplotypes_num);
     size_t hap_total = 0;
     for (size_t j = 0; j < haplotypes_num; ++j) {
-        st.hap_off[j] = (uint32_t)hap_total;
-        st.hap_len[j] = hs[j]->get_display_string()->num;
-        hap_total += st.hap_len[j];
+        hap_off[j] = (uint32_t)hap_total;
+        hap_len[j] = hs[j]->get_display_string()->num;
+        hap_total += hap_len[j];
     }
-    st.hap_bases.resize(hap_total);
-    for (size_t j = 0; j < haplotypes_num; ++j)
-        memcpy(st.hap_bases.data() + st.hap_off[j], hs[j]->get_display_string()->data, st.hap_len[j]);
-
-    // ---- the device: all reads x all haplotypes, (read, hap) order ----
+    std::vector<uint8_t> hap_bases(hap_total);
+    for (size_t j = 0; j < haplotypes_num; ++j) memcpy(hap_bases.data() + hap_off[j], hs[j]->get_display_string()->data, hap_len[j]);
     st.likelihood.resize(reads_num * haplotypes_num);
-    const int model = static_cast<int>(pcr_option);
-    if (g_batching.load() && !g_batchers.empty()) {
-        RegionJob &job = st.job;
-        job.bases = st.bases.data();
-        job.quals = st.quals.data();
-        job.mapq = st.mapq.data();
-        job.hap_bases = st.hap_bases.data();
-        job.read_off = st.read_off.data();
-        job.read_len = st.read_len.data();
-        job.hap_off = st.hap_off.data();
-        job.hap_len = st.hap_len.data();
-        job.n_reads = (uint32_t)reads_num;
-        job.n_haps = (uint32_t)haplotypes_num;
-        job.read_bytes = total;
-        job.hap_bytes = hap_total;
-        job.min_q = min_quality_threshold;
-        job.pcr_model = model;
-        job.out = st.likelihood.data();
-        st.batcher = g_batchers[g_next_batcher.fetch_add(1) % g_batchers.size()];
-        st.batcher->submit(job);
-    }
-    else {
-        phmm_read_prep prep{st.mapq.data(), min_quality_threshold, model, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
-        phmm_batch b{};
-        b.n_reads = (uint32_t)reads_num;
-        b.n_haps = (uint32_t)haplotypes_num;
-        b.n_pairs = (uint64_t)reads_num * haplotypes_num;
-        b.read_bases = st.bases.data();
-        b.read_qual = st.quals.data();
-        b.read_off = st.read_off.data();
-        b.read_len = st.read_len.data();
-        b.hap_bases = st.hap_bases.data();
-        b.hap_off = st.hap_off.data();
-        b.hap_len = st.hap_len.data();
-        b.prep = &prep;
-        st.rc = phmm_compute(t_ctx.get(), &b, nullptr, st.likelihood.data(), nullptr);
-        if (st.rc != PHMM_OK) snprintf(st.why, sizeof(st.why), "%s", phmm_last_error());
-    }
+    phmm_read_prep prep{mapq.data(), min_quality_threshold, model, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
+    phmm_batch b{};
+    b.n_reads = (uint32_t)reads_num;
+    b.n_haps = (uint32_t)haplotypes_num;
+    b.n_pairs = (uint64_t)reads_num * haplotypes_num;
+    b.read_bases = bases.data();
+    b.read_qual = quals.data();
+    b.read_off = read_off.data();
+    b.read_len = read_len.data();
+    b.hap_bases = hap_bases.data();
+    b.hap_off = hap_off.data();
+    b.hap_len = hap_len.data();
+    b.prep = &prep;
+    st.rc = phmm_compute(t_ctx.get(), &b, nullptr, st.likelihood.data(), nullptr);  // all reads x all haplotypes, (read, hap) order
+    if (st.rc != PHMM_OK) snprintf(st.why, sizeof(st.why), "%s", phmm_last_error());
     return t;
 }
 
@@ -465,10 +548,33 @@ DoubleVector2D call_gpu_pairhmm_finish(PairhmmTicket &&ticket, ReadVector &rs, p
     }
     // the result comes from the caller's arena (pairhmm_internal.cpp:516)
     DoubleVector2D final_likelihood{haplotypes_num, DoubleVector{reads_num, NAN, pool}, pool};
+    static thread_local std::vector<double> scratch;
+    static thread_local std::vector<int32_t> scratch_len;
+    double *likelihood_array = nullptr;
+    const int32_t *seq_len = nullptr;
     if (st.batcher) {
-        st.rc = st.batcher->wait(st.job);
-        if (st.rc != PHMM_OK) snprintf(st.why, sizeof(st.why), "%s", st.job.error);
+        // the region's sums are in the stage: convert them here, on the worker (pairhmm_internal.cpp:577-585), then let go of the stage
+        StageSlot &slot = *st.rv.slot;
+        ProfClock clk;
+        st.rc = RegionBatcher::wait(slot);
+        clk.lap(kProfWaitResults);
+        if (st.rc != PHMM_OK) snprintf(st.why, sizeof(st.why), "%s", slot.error);
+        if (st.rc == PHMM_OK) {
+            scratch.resize(reads_num * haplotypes_num);
+            scratch_len.resize(reads_num);
+            st.rc = phmm_stage_log10(slot.st, phmm_stage_pair_first(slot.st, st.rv.region), reads_num * haplotypes_num, scratch.data(), nullptr, nullptr);
+            if (st.rc != PHMM_OK) snprintf(st.why, sizeof(st.why), "%s", phmm_last_error());
+            for (size_t i = 0; i < reads_num; ++i) scratch_len[i] = (int32_t)slot.v.read_len[st.rv.read_first + i];
+        }
+        st.batcher->release(slot);
+        clk.lap(kProfConvert);
         st.batcher = nullptr;  // nothing of the ticket is in flight any more
+        likelihood_array = scratch.data();
+        seq_len = scratch_len.data();
+    }
+    else {
+        likelihood_array = st.likelihood.data();
+        seq_len = st.seq_len.data();
     }
     if (st.rc != PHMM_OK) {
         fprintf(stderr, "[rovaca_amd] pairhmm: device evaluation failed (status %d): %s\n", st.rc, st.why);
@@ -476,9 +582,17 @@ DoubleVector2D call_gpu_pairhmm_finish(PairhmmTicket &&ticket, ReadVector &rs, p
     }
 
     // ---- post-processing (pairhmm_internal.cpp:589-591) ----
-    double *likelihood_array = st.likelihood.data();
+    struct PostClock : ProfClock
+    {
+        ~PostClock() { lap(kProfPostprocess); }
+    } post_clock;
     rovaca_amd::normalize_likelihoods(likelihood_array, reads_num, haplotypes_num);
-    const std::vector<size_t> drop = rovaca_amd::poorly_modelled_reads(likelihood_array, st.seq_len.data(), reads_num, haplotypes_num);
+    const std::vector<size_t> drop = rovaca_amd::poorly_modelled_reads(likelihood_array, seq_len, reads_num, haplotypes_num);
+    if (drop.empty()) {
+        for (size_t i = 0; i < reads_num; ++i)
+            for (size_t j = 0; j < haplotypes_num; ++j) final_likelihood[j][i] = likelihood_array[i * haplotypes_num + j];
+        return final_likelihood;
+    }
     std::vector<char> dropped(reads_num, 0);
     for (size_t r : drop) dropped[r] = 1;
     for (auto it = drop.rbegin(); it != drop.rend(); ++it) rs.erase(rs.begin() + (std::ptrdiff_t)*it);  // back to front, :178-181

@@ -68,6 +68,10 @@ bool init_pairhmm_ptr_gpu(int device_id = -1);
 // call_pairhmm concurrently are coalesced into one device batch per round trip.  ROVACA_AMD_PAIRHMM_BATCHING=0 disables it.
 void gpu_pairhmm_batching_stats(uint64_t *regions, uint64_t *submissions);
 
+// Where the adapter's host time went so far: seconds per phase summed over all worker and dispatcher threads (names[i] describes
+// seconds[i]); returns the number of phases.  tools/adapter_bench.cpp prints it; profiles/ keeps a run.
+int gpu_pairhmm_profile(double *seconds, const char **names, int cap);
+
 // the step right after the seam.  One sample of AlleleLikelihoods::marginal_likelihoods_direct
 // (genotype/allele_likelihoods.hpp:702-732): the read x haplotype matrix collapsed onto a smaller allele set by a maximum
 // over the old alleles that map to each new one.  Same values, bit for bit (a maximum of doubles); the rows of the result

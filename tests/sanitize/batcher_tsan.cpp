@@ -50,11 +50,74 @@ int phmm_create(int, void *, phmm_context **out)
 void phmm_destroy(phmm_context *c) { delete c; }
 int phmm_compute(phmm_context *, const phmm_batch *b, float *, double *out_log10, phmm_stats *)
 {
-    std::this_thread::sleep_for(std::chrono::microseconds(150));  // a device round trip: lets submissions pile up
-    for (uint64_t p = 0; p < b->n_pairs; ++p) {
-        const uint32_t r = b->pair_read[p], h = b->pair_hap[p];
-        out_log10[p] = fake_likelihood(b->read_bases + b->read_off[r], b->read_len[r], b->hap_bases + b->hap_off[h], b->hap_len[h]);
+    // the direct path (a region that fits no stage): the full cross product in (read, hap) order
+    std::this_thread::sleep_for(std::chrono::microseconds(150));
+    for (uint32_t r = 0; r < b->n_reads; ++r)
+        for (uint32_t h = 0; h < b->n_haps; ++h)
+            out_log10[(size_t)r * b->n_haps + h] =
+                fake_likelihood(b->read_bases + b->read_off[r], b->read_len[r], b->hap_bases + b->hap_off[h], b->hap_len[h]);
+    return PHMM_OK;
+}
+// stand-in stage: ordinary memory laid out like the real one, "results" computed at submit
+struct phmm_stage
+{
+    phmm_stage_caps caps;
+    std::vector<uint8_t> bytes, mq;
+    std::vector<uint32_t> roff, qoff, rlen, hoff, hlen;
+    std::vector<phmm_region> reg;
+    std::vector<double> out;
+    std::vector<uint64_t> first;
+};
+int phmm_stage_create(phmm_context *, const phmm_stage_caps *k, phmm_stage **out)
+{
+    phmm_stage *s = new phmm_stage();
+    s->caps = *k;
+    s->bytes.resize(k->max_bytes);
+    s->mq.resize(k->max_reads);
+    s->roff.resize(k->max_reads);
+    s->qoff.resize(k->max_reads);
+    s->rlen.resize(k->max_reads);
+    s->hoff.resize(k->max_haps);
+    s->hlen.resize(k->max_haps);
+    s->reg.resize(k->max_regions);
+    s->out.resize(k->max_pairs);
+    s->first.resize((size_t)k->max_regions + 1);
+    *out = s;
+    return PHMM_OK;
+}
+void phmm_stage_destroy(phmm_context *, phmm_stage *s) { delete s; }
+int phmm_stage_get_view(const phmm_stage *cs, phmm_stage_view *v, phmm_stage_caps *k)
+{
+    phmm_stage *s = const_cast<phmm_stage *>(cs);
+    *v = phmm_stage_view{s->bytes.data(), s->roff.data(), s->qoff.data(), s->rlen.data(), s->mq.data(), s->hoff.data(), s->hlen.data(), s->reg.data()};
+    if (k) *k = s->caps;
+    return PHMM_OK;
+}
+int phmm_stage_submit(phmm_context *, phmm_stage *s, uint32_t n_regions, uint32_t n_reads, uint32_t n_haps, const phmm_stage_params *)
+{
+    uint64_t p = 0;
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        const phmm_region &rg = s->reg[g];
+        if (rg.read_first + rg.n_reads > n_reads || rg.hap_first + rg.n_haps > n_haps) return PHMM_E_INVALID;
+        s->first[g] = p;
+        for (uint32_t r = rg.read_first; r < rg.read_first + rg.n_reads; ++r) {
+            if (s->qoff[r] != s->roff[r] + s->rlen[r]) return PHMM_E_INVALID;  // the adapter puts a read's qualities behind its bases
+            for (uint32_t h = rg.hap_first; h < rg.hap_first + rg.n_haps; ++h)
+                s->out[p++] = fake_likelihood(s->bytes.data() + s->roff[r], s->rlen[r], s->bytes.data() + s->hoff[h], s->hlen[h]);
+        }
     }
+    s->first[n_regions] = p;
+    return PHMM_OK;
+}
+int phmm_stage_wait(phmm_context *, phmm_stage *, phmm_stats *)
+{
+    std::this_thread::sleep_for(std::chrono::microseconds(150));  // a device round trip: lets regions pile up in the open stage
+    return PHMM_OK;
+}
+uint64_t phmm_stage_pair_first(const phmm_stage *s, uint32_t region) { return s->first[region]; }
+int phmm_stage_log10(const phmm_stage *s, uint64_t first_pair, uint64_t n, double *out, float *, uint64_t *)
+{
+    for (uint64_t p = 0; p < n; ++p) out[p] = s->out[first_pair + p];
     return PHMM_OK;
 }
 int swhip_abi_version(void) { return SWHIP_ABI_VERSION; }

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/pairhmm_hip.h but not exported"
     assert set(names) == set(capi.EXPORTS)
-    assert capi.lib().phmm_abi_version() == 4
+    assert capi.lib().phmm_abi_version() == 5
 
 
 def test_product_tables_equal_reference_tables(golden):
