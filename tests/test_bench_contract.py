@@ -41,3 +41,8 @@ def test_device_line_has_roofline_and_cpu_baseline():
     assert base["bit_identical_to_gpu_fp32"] is True and d["max_abs_delta_log10_vs_cpu"] == 0.0
     assert d["e2e"]["identical_to_resident_path"] is True and d["e2e"]["value"] > 0
     assert d["pcr_capped_gap_open"]["kernel_gcups"] > 0
+    # the drop-in adapter leg: workers -> rovaca::call_pairhmm -> batcher -> device -> H8, checked against the resident path
+    ad = d["adapter"]
+    assert "error" not in ad, ad
+    assert ad["bit_identical_to_resident_path"] is True and ad["value"] > 0 and ad["synchronous_seam"]["value"] > 0
+    assert ad["workers"] >= 1 and ad["regions_per_submission"] >= 1.0 and ad["regions"] == ad["workers"] * 2000
