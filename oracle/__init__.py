@@ -156,6 +156,38 @@ def batch(b, n_threads=1, want_raw=True):
     return raw, l10, resc.astype(bool)
 
 
+_F128 = None
+
+
+def f128_lib():
+    """The __float128 statement of the recurrence (oracle/phmm_oracle_f128.c), independent of phmm_oracle.c."""
+    global _F128
+    if _F128 is None:
+        path = os.path.join(_HERE, "_build", "libphmm_oracle_f128.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+        f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        L.phmm_f128_pair_log10.argtypes = [u8p, u8p, u8p, u8p, u8p, C.c_uint32, u8p, C.c_uint32, f64p, f64p, C.POINTER(C.c_int)]
+        L.phmm_f128_pair_log10.restype = C.c_double
+        _F128 = L
+    return _F128
+
+
+def pair_f128_log10(b, p, tabs=None):
+    """log10 likelihood of pair p of batch b in 113-bit arithmetic, and whether a double at the 2^1020 scale has underflowed to 0."""
+    t = tabs or tables()
+    r, h = int(b.pair_read[p]), int(b.pair_hap[p])
+    ro, rl, ho, hl = int(b.read_off[r]), int(b.read_len[r]), int(b.hap_off[h]), int(b.hap_len[h])
+    c = lambda a, o, n: np.ascontiguousarray(a[o:o + n])
+    below = C.c_int(0)
+    v = f128_lib().phmm_f128_pair_log10(c(b.read_bases, ro, rl), c(b.read_qual, ro, rl), c(b.read_ins, ro, rl), c(b.read_del, ro, rl),
+                                        c(b.read_gcp, ro, rl), rl, c(b.hap_bases, ho, hl), hl, np.ascontiguousarray(t["ph2pr_f64"]),
+                                        np.ascontiguousarray(t["mm_f64"]), C.byref(below))
+    return v, bool(below.value)
+
+
 def prepare_batch(b, mapq, min_q=18, pcr_model=3, gap_open=45, gap_cont=10):
     """The read table of a batch with RAW qualities as the reference's decompression_data leaves it (pairhmm_internal.cpp:413-448):
     phmm_oracle_modify_quals (H3) and phmm_oracle_apply_pcr_error_model (H4) per read, deletion gap-opens aliasing the insertion
