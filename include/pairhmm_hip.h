@@ -200,10 +200,16 @@ int phmm_plan_region_bins(const phmm_batch *tables, const phmm_region *regions, 
  * haplotype length, index) and divided into n_devices contiguous slices of equal DP cells; every device works its slice on
  * its own host thread, with its own context (stream set, pinned staging, tables), and writes results at the pairs' own
  * positions of the caller's arrays.  A phmm_context stays one-device by contract (phmm_create); this handle owns one per
- * listed device.  device_ids must be distinct. */
+ * listed device.  device_ids must be distinct -- unless PHMM_MULTI_ALLOW_SHARED_DEVICE is set in the environment (a test and
+ * rehearsal hook: every entry still gets its own context, host thread and slice, so the N-slice path can be run on a box with
+ * fewer than N GPUs; bench.py --oversubscribe uses it and keeps reporting the number of PHYSICAL devices).  Every device receives
+ * only the reads and haplotypes its slice refers to. */
 typedef struct phmm_multi phmm_multi;
 typedef struct phmm_multi_resident phmm_multi_resident;
 int phmm_create_multi(const int *device_ids, int n_devices, phmm_multi **out);
+/* the same handle over n_slices CPU contexts (phmm_create_cpu): the cut, the per-slice threads, the scatter and the timed gate are
+ * the code the device slices run -- the N > 1 path on a machine without GPUs.  phmm_multi_device_id reports -1, -2, ... */
+int phmm_create_multi_cpu(int n_slices, int n_threads_each, int allow_simd, phmm_multi **out);
 void phmm_destroy_multi(phmm_multi *m);
 int phmm_multi_device_count(const phmm_multi *m);
 int phmm_multi_device_id(const phmm_multi *m, int i); /* HIP device of slice i, -1 when out of range */

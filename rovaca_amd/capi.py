@@ -21,7 +21,7 @@ EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy
            "phmm_create_multi", "phmm_destroy_multi", "phmm_multi_device_count", "phmm_multi_device_id", "phmm_multi_compute",
            "phmm_multi_upload", "phmm_multi_sweep", "phmm_multi_synchronize", "phmm_multi_sweep_timed", "phmm_multi_download",
            "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize", "phmm_create_cpu", "phmm_backend_name", "phmm_plan_slices",
-           "phmm_compute_regions", "phmm_stage_create", "phmm_stage_destroy", "phmm_stage_get_view", "phmm_stage_submit", "phmm_stage_wait",
+           "phmm_create_multi_cpu", "phmm_compute_regions", "phmm_stage_create", "phmm_stage_destroy", "phmm_stage_get_view", "phmm_stage_submit", "phmm_stage_wait",
            "phmm_stage_pair_first", "phmm_stage_log10", "phmm_plan_bins", "phmm_plan_region_bins")
 
 
@@ -137,6 +137,8 @@ def lib():
     L.phmm_create_cpu.restype = C.c_int
     L.phmm_backend_name.argtypes = [C.c_void_p]
     L.phmm_backend_name.restype = C.c_char_p
+    L.phmm_create_multi_cpu.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.phmm_create_multi_cpu.restype = C.c_int
     L.phmm_compute_regions.argtypes = [C.c_void_p, C.POINTER(PhmmBatch), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(PhmmStats)]
     L.phmm_compute_regions.restype = C.c_int
     L.phmm_stage_create.argtypes = [C.c_void_p, C.POINTER(PhmmStageCaps), C.POINTER(C.c_void_p)]
@@ -482,11 +484,16 @@ class MultiEngine:
     """Several devices behind one handle (phmm_create_multi): the pair list is cut into equal-cells slices, one host thread
     and one context per device, no collective."""
 
-    def __init__(self, devices):
-        devices = [int(d) for d in devices]
-        arr = (C.c_int * len(devices))(*devices)
+    def __init__(self, devices=None, cpu_slices=0, cpu_threads_each=1):
+        """devices: HIP device ids (distinct, unless PHMM_MULTI_ALLOW_SHARED_DEVICE is set); or cpu_slices > 0 for a handle over
+        CPU contexts (phmm_create_multi_cpu)."""
         h = C.c_void_p()
-        _check(lib().phmm_create_multi(arr, len(devices), C.byref(h)), "phmm_create_multi")
+        if cpu_slices:
+            _check(lib().phmm_create_multi_cpu(int(cpu_slices), int(cpu_threads_each), 1, C.byref(h)), "phmm_create_multi_cpu")
+        else:
+            devices = [int(d) for d in devices]
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().phmm_create_multi(arr, len(devices), C.byref(h)), "phmm_create_multi")
         self.handle = h
         self.n_devices = lib().phmm_multi_device_count(h)
         self.devices = [lib().phmm_multi_device_id(h, i) for i in range(self.n_devices)]

@@ -1326,7 +1326,10 @@ int phmm_create_multi(const int *device_ids, int n_devices, phmm_multi **out)
 {
     if (!out || !device_ids || n_devices < 1) return fail(PHMM_E_INVALID, "phmm_create_multi: bad arguments");
     *out = nullptr;
-    for (int i = 0; i < n_devices; ++i)
+    // PHMM_MULTI_ALLOW_SHARED_DEVICE=1 (tests, and bench.py --oversubscribe): a device may be listed several times -- every
+    // entry still gets its own context, host thread and slice, so the whole N-slice path runs on a box with fewer than N GPUs
+    const bool shared_ok = getenv("PHMM_MULTI_ALLOW_SHARED_DEVICE") != nullptr;
+    for (int i = 0; i < n_devices && !shared_ok; ++i)
         for (int j = 0; j < i; ++j)
             if (device_ids[i] == device_ids[j])
                 return fail(PHMM_E_INVALID, "phmm_create_multi: device %d is listed twice (one context per device)", device_ids[i]);
@@ -1338,6 +1341,27 @@ int phmm_create_multi(const int *device_ids, int n_devices, phmm_multi **out)
             impl::phmm_destroy_multi(m);
             return rc;
         }
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return PHMM_OK;
+}
+
+// the same handle over CPU contexts (phmm_create_cpu): the cut, the per-slice threads, the scatter of the results and the timed
+// gate are the code the device slices run, so the N > 1 path is exercised on a machine without GPUs
+int phmm_create_multi_cpu(int n_slices, int n_threads_each, int allow_simd, phmm_multi **out)
+{
+    if (!out || n_slices < 1 || n_threads_each < 0) return fail(PHMM_E_INVALID, "phmm_create_multi_cpu: bad arguments");
+    *out = nullptr;
+    phmm_multi *m = new phmm_multi();
+    for (int i = 0; i < n_slices; ++i) {
+        phmm_context *c = nullptr;
+        const int rc = impl::phmm_create_cpu(n_threads_each, allow_simd, &c);
+        if (rc != PHMM_OK) {
+            impl::phmm_destroy_multi(m);
+            return rc;
+        }
+        c->device = -1 - i;  // (only a label: phmm_multi_device_id reports -1, -2, ... for CPU slices)
         m->ctx.push_back(c);
     }
     *out = m;
@@ -1360,7 +1384,11 @@ static int partition_equal_cells(const phmm_batch *b, size_t n_dev, phmm_multi_r
     const bool cross = b->pair_read == nullptr;
     const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
     if (n > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_multi_upload: more than 2^32 pairs in one batch");
-    if (n && (!b->read_len || !b->hap_len)) return fail(PHMM_E_INVALID, "phmm_multi_upload: null table pointer");
+    if (n && (!b->read_len || !b->hap_len || !b->read_off || !b->hap_off || !b->read_bases || !b->read_qual || !b->hap_bases))
+        return fail(PHMM_E_INVALID, "phmm_multi_upload: null table pointer");
+    if (n && !b->prep && (!b->read_ins || !b->read_del || !b->read_gcp))
+        return fail(PHMM_E_INVALID, "phmm_multi_upload: null gap-penalty array (and no phmm_read_prep given)");
+    if (b->prep && (!b->prep->read_mapq || b->prep->pcr_model < 0 || b->prep->pcr_model > 3)) return fail(PHMM_E_INVALID, "phmm_multi_upload: bad phmm_read_prep");
     rb->n_pairs = n;
     std::vector<uint64_t> keys(n);
     std::atomic<uint64_t> bad{UINT64_MAX};
@@ -1428,15 +1456,76 @@ static int partition_equal_cells(const phmm_batch *b, size_t n_dev, phmm_multi_r
     return PHMM_OK;
 }
 
-static phmm_batch slice_of(const phmm_batch *b, const phmm_multi_resident *rb, size_t g)
+// A slice as a batch of its own: only the reads and haplotypes its pairs refer to, packed into tables of its own (a slice is a
+// run of the length-binned ORDER, so its reads lie all over the caller's tables: windows would not do), indices remapped.  Every
+// device therefore packs, uploads and prepares its own share of the tables instead of the whole batch (round 2 handed every
+// device the full tables: N times the upload and N times the haplotype planes).
+struct SliceTables
 {
-    phmm_batch s = *b;
-    s.n_pairs = rb->index[g].size();
-    // an empty slice still needs non-null pair arrays, or it would read as "full cross product"
-    static const uint32_t none = 0;
-    s.pair_read = rb->pr[g].empty() ? &none : rb->pr[g].data();
-    s.pair_hap = rb->ph[g].empty() ? &none : rb->ph[g].data();
-    return s;
+    std::vector<uint8_t> bases, qual, ins, del, gcp, mapq, haps;
+    std::vector<uint32_t> roff, rlen, hoff, hlen, pr, ph;
+    phmm_read_prep prep{};
+    phmm_batch view{};
+};
+static void slice_of(const phmm_batch *b, const phmm_multi_resident *rb, size_t g, SliceTables &t)
+{
+    const std::vector<uint32_t> &gpr = rb->pr[g], &gph = rb->ph[g];
+    const size_t n = gpr.size();
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    std::vector<uint32_t> rmap(b->n_reads, kNone), hmap(b->n_haps, kNone);
+    t.pr.resize(n ? n : 1);
+    t.ph.resize(n ? n : 1);
+    const bool has_gap_arrays = b->prep == nullptr;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t r = gpr[i], h = gph[i];
+        if (rmap[r] == kNone) {
+            rmap[r] = (uint32_t)t.rlen.size();
+            const uint32_t o = b->read_off[r], len = b->read_len[r];
+            t.roff.push_back((uint32_t)t.bases.size());
+            t.rlen.push_back(len);
+            t.bases.insert(t.bases.end(), b->read_bases + o, b->read_bases + o + len);
+            t.qual.insert(t.qual.end(), b->read_qual + o, b->read_qual + o + len);
+            if (has_gap_arrays) {
+                t.ins.insert(t.ins.end(), b->read_ins + o, b->read_ins + o + len);
+                t.del.insert(t.del.end(), b->read_del + o, b->read_del + o + len);
+                t.gcp.insert(t.gcp.end(), b->read_gcp + o, b->read_gcp + o + len);
+            }
+            else {
+                t.mapq.push_back(b->prep->read_mapq[r]);
+            }
+        }
+        if (hmap[h] == kNone) {
+            hmap[h] = (uint32_t)t.hlen.size();
+            const uint32_t o = b->hap_off[h], len = b->hap_len[h];
+            t.hoff.push_back((uint32_t)t.haps.size());
+            t.hlen.push_back(len);
+            t.haps.insert(t.haps.end(), b->hap_bases + o, b->hap_bases + o + len);
+        }
+        t.pr[i] = rmap[r];
+        t.ph[i] = hmap[h];
+    }
+    phmm_batch &s = t.view;
+    s = phmm_batch{};
+    s.n_reads = (uint32_t)t.rlen.size();
+    s.n_haps = (uint32_t)t.hlen.size();
+    s.n_pairs = n;
+    s.read_bases = t.bases.data();
+    s.read_qual = t.qual.data();
+    s.read_ins = has_gap_arrays ? t.ins.data() : nullptr;
+    s.read_del = has_gap_arrays ? t.del.data() : nullptr;
+    s.read_gcp = has_gap_arrays ? t.gcp.data() : nullptr;
+    s.read_off = t.roff.data();
+    s.read_len = t.rlen.data();
+    s.hap_bases = t.haps.data();
+    s.hap_off = t.hoff.data();
+    s.hap_len = t.hlen.data();
+    s.pair_read = t.pr.data();  // (never null: an empty slice must not read as "full cross product")
+    s.pair_hap = t.ph.data();
+    if (b->prep) {
+        t.prep = *b->prep;
+        t.prep.read_mapq = t.mapq.data();
+        s.prep = &t.prep;
+    }
 }
 
 int phmm_multi_upload(phmm_multi *m, const phmm_batch *b, phmm_multi_resident **out)
@@ -1448,8 +1537,9 @@ int phmm_multi_upload(phmm_multi *m, const phmm_batch *b, phmm_multi_resident **
     if (rc == PHMM_OK) {
         rb->part.assign(m->ctx.size(), nullptr);
         rc = on_every_device(m, [&](size_t g) {
-            const phmm_batch s = slice_of(b, rb, g);
-            return impl::phmm_upload(m->ctx[g], &s, &rb->part[g]);
+            SliceTables t;  // (the upload copies what it needs: the slice's tables may go when it returns)
+            slice_of(b, rb, g, t);
+            return impl::phmm_upload(m->ctx[g], &t.view, &rb->part[g]);
         });
     }
     if (rc != PHMM_OK) {
@@ -1563,11 +1653,12 @@ int phmm_multi_compute(phmm_multi *m, const phmm_batch *b, float *out_raw_f32, d
     const size_t n = m->ctx.size();
     std::vector<phmm_stats> st(n);
     rc = on_every_device(m, [&](size_t g) -> int {
-        const phmm_batch s = slice_of(b, &part, g);
+        SliceTables t;
+        slice_of(b, &part, g, t);
         const size_t k = part.index[g].size();
         std::vector<float> raw(out_raw_f32 ? k : 0);
         std::vector<double> l10(out_log10 ? k : 0);
-        const int r = impl::phmm_compute(m->ctx[g], &s, out_raw_f32 ? raw.data() : nullptr, out_log10 ? l10.data() : nullptr, &st[g]);
+        const int r = impl::phmm_compute(m->ctx[g], &t.view, out_raw_f32 ? raw.data() : nullptr, out_log10 ? l10.data() : nullptr, &st[g]);
         if (r != PHMM_OK) return r;
         const uint32_t *idx = part.index[g].data();
         if (out_raw_f32)
@@ -1790,6 +1881,10 @@ int phmm_marginalize(phmm_context *c, const double *old, uint32_t n_old, uint32_
 int phmm_create_multi(const int *device_ids, int n, phmm_multi **out)
 {
     return guarded("phmm_create_multi", [&] { return impl::phmm_create_multi(device_ids, n, out); });
+}
+int phmm_create_multi_cpu(int n_slices, int n_threads_each, int allow_simd, phmm_multi **out)
+{
+    return guarded("phmm_create_multi_cpu", [&] { return impl::phmm_create_multi_cpu(n_slices, n_threads_each, allow_simd, out); });
 }
 void phmm_destroy_multi(phmm_multi *m)
 {

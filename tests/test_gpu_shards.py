@@ -92,37 +92,57 @@ def test_compute_sharded_two_ranks_sharing_the_card(engine, tmp_path):
     assert np.array_equal(got["l10"], l10)
 
 
-def test_multi_device_handle(engine):
-    # the C-ABI form of the same split (one host thread and one context per device); a 1-GPU box exercises it with one slice,
-    # and with as many as there are devices elsewhere
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_multi_device_handle(engine, n, monkeypatch):
+    # the C-ABI form of the same split (one host thread and one context per slice).  On a box with fewer than n GPUs the slices
+    # share the card (PHMM_MULTI_ALLOW_SHARED_DEVICE, a hook for exactly this): n contexts, n host threads, n slices of the cut,
+    # the common start gate of the timed sweep, the scatter to the pairs' own positions -- everything an 8-GPU run does but the PCIe
     n_dev = capi.lib().phmm_device_count()
+    devices = list(range(n)) if n <= n_dev else [i % n_dev for i in range(n)]
+    if n > n_dev:
+        monkeypatch.setenv("PHMM_MULTI_ALLOW_SHARED_DEVICE", "1")
     b = _mixed_batch()
     raw, l10, st = engine.compute(b)
-    for n in sorted({1, n_dev}):
-        m = capi.MultiEngine(list(range(n)))
-        assert m.n_devices == n and m.devices == list(range(n))
-        mraw, ml10, mst = m.compute(b)
-        assert np.array_equal(mraw.view(np.uint32), raw.view(np.uint32)) and np.array_equal(ml10, l10)
-        assert int(mst.cells) == b.cells() and int(mst.n_rescued) == int(st.n_rescued)
-        rb = m.upload(b)
-        cells, pairs = rb.shard_cells()
-        assert int(cells.sum()) == b.cells() and int(pairs.sum()) == b.n_pairs
-        assert int(cells.max()) - int(cells.min()) <= 2 * 250 * 500  # each cut within one pair of the ideal
-        rb.sweep()
-        wall, dev, f32 = rb.sweep_timed(2)
-        assert wall > 0 and (dev > 0).all()
-        rraw, rl10, _ = rb.download()
-        assert np.array_equal(rraw.view(np.uint32), raw.view(np.uint32)) and np.array_equal(rl10, l10)
-        rb.release()
-        # the full cross product form (pair arrays NULL) goes through the same cut
-        cross = Batch(b.read_bases, b.read_qual, b.read_ins, b.read_del, b.read_gcp, b.read_off[:40], b.read_len[:40],
-                      b.hap_bases, b.hap_off[:9], b.hap_len[:9], np.repeat(np.arange(40), 9), np.tile(np.arange(9), 40))
-        craw, _, _ = m.compute(cross, cross=True)
-        eraw, _, _ = engine.compute(cross)
-        assert np.array_equal(craw.view(np.uint32), eraw.view(np.uint32))
-        m.close()
+    m = capi.MultiEngine(devices)
+    assert m.n_devices == n and m.devices == devices
+    mraw, ml10, mst = m.compute(b)
+    assert np.array_equal(mraw.view(np.uint32), raw.view(np.uint32)) and np.array_equal(ml10, l10)
+    assert int(mst.cells) == b.cells() and int(mst.n_rescued) == int(st.n_rescued)
+    rb = m.upload(b)
+    cells, pairs = rb.shard_cells()
+    assert int(cells.sum()) == b.cells() and int(pairs.sum()) == b.n_pairs and (pairs > 0).all()
+    assert int(cells.max()) - int(cells.min()) <= 2 * 250 * 500  # each cut within one pair of the ideal
+    which, pcells = capi.plan_slices(b, n)
+    assert [int(c) for c in pcells] == [int(c) for c in cells]
+    rb.sweep()
+    wall, dev, f32 = rb.sweep_timed(2)
+    assert wall > 0 and (dev > 0).all() and (f32 > 0).all() and wall < 100 * dev.max()
+    rraw, rl10, _ = rb.download()
+    assert np.array_equal(rraw.view(np.uint32), raw.view(np.uint32)) and np.array_equal(rl10, l10)
+    rb.release()
+    # a shuffled pair list: results land at the pairs' own positions
+    perm = np.random.default_rng(6).permutation(b.n_pairs)
+    praw, _, _ = m.compute(b.subset(perm))
+    assert np.array_equal(praw.view(np.uint32), raw[perm].view(np.uint32))
+    # the full cross product form (pair arrays NULL) goes through the same cut
+    cross = Batch(b.read_bases, b.read_qual, b.read_ins, b.read_del, b.read_gcp, b.read_off[:40], b.read_len[:40],
+                  b.hap_bases, b.hap_off[:9], b.hap_len[:9], np.repeat(np.arange(40), 9), np.tile(np.arange(9), 40))
+    craw, _, _ = m.compute(cross, cross=True)
+    eraw, _, _ = engine.compute(cross)
+    assert np.array_equal(craw.view(np.uint32), eraw.view(np.uint32))
+    # raw qualities: every slice prepares its own reads on its device
+    mapq = np.random.default_rng(7).choice(np.array([60, 29, 12], np.uint8), b.n_reads)
+    qraw, ql10, _ = m.compute(b, prep=(mapq, 18, 3))
+    eraw, el10, _ = engine.compute(b, prep=(mapq, 18, 3))
+    assert np.array_equal(qraw.view(np.uint32), eraw.view(np.uint32)) and np.array_equal(ql10, el10, equal_nan=True)
+    m.close()
+
+
+def test_multi_device_handle_rejects_bad_device_lists(monkeypatch):
+    n_dev = capi.lib().phmm_device_count()
+    monkeypatch.delenv("PHMM_MULTI_ALLOW_SHARED_DEVICE", raising=False)
     with pytest.raises(capi.PhmmError):
-        capi.MultiEngine([0, 0])  # one context per device
+        capi.MultiEngine([0, 0])  # one context per device (without the rehearsal hook)
     with pytest.raises(capi.PhmmError):
         capi.MultiEngine([n_dev])  # no such device
 
@@ -136,10 +156,14 @@ def test_bench_refuses_more_gpus_than_there_are():
                         "--warmup", "1", "--scale", "0.02", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
+    # the rehearsal runs n_dev + 1 SLICES (the whole N-slice path) on the devices there are and says so: n_gpus stays physical
     assert line["n_gpus"] == n_dev and line["metric"] == "PairHMM GCUPS" and line["value"] > 0
+    assert line["config"]["slices"] == n_dev + 1 and len(line["per_device_ms_per_step"]) == n_dev + 1 and "note" in line
+    assert line["roofline_valu"]["frac"] > 0 and line["imbalance_max_over_mean"] >= 1.0 and "traffic_source" in line["roofline"]
+    assert sum(line["config"]["shard_cells"]) == line["config"]["cells_per_gpu"] * line["config"]["slices"]
 
 
-def test_config4_chunked_resident_batch(engine):
+def test_config4_chunked_resident_batch(engine, monkeypatch):
     # BASELINE config 4 as bench.py --config c4 runs it on one GPU: the pair stream is kept resident in chunks (one upload
     # each), a step sweeps every chunk.  Two chunks of config 4's length distribution here; a seeded sample of every chunk
     # against the oracle, and the order of the pair list must not matter.
@@ -163,12 +187,22 @@ def test_config4_chunked_resident_batch(engine):
         rp.release()
         assert np.array_equal(praw.view(np.uint32), raw[perm].view(np.uint32)) and np.array_equal(pl10, l10[perm], equal_nan=True)
         r.release()
-    # the same stream cut across devices instead of chunks
-    m = capi.MultiEngine(list(range(capi.lib().phmm_device_count())))
-    mraw, _, _ = m.compute(chunks[0])
-    eraw, _, _ = engine.compute(chunks[0])
-    assert np.array_equal(mraw.view(np.uint32), eraw.view(np.uint32))
-    m.close()
+    # the same stream cut across slices instead of chunks: as many devices as there are, and two and three slices whatever there is
+    eraw, el10, _ = engine.compute(chunks[0])
+    n_dev = capi.lib().phmm_device_count()
+    monkeypatch.setenv("PHMM_MULTI_ALLOW_SHARED_DEVICE", "1")
+    for n in sorted({n_dev, 2, 3}):
+        m = capi.MultiEngine([i % n_dev for i in range(n)])
+        mraw, ml10, _ = m.compute(chunks[0])
+        assert np.array_equal(mraw.view(np.uint32), eraw.view(np.uint32)) and np.array_equal(ml10, el10, equal_nan=True)
+        rb = m.upload(chunks[0])
+        cells, _ = rb.shard_cells()
+        assert int(cells.sum()) == chunks[0].cells() and int(cells.max()) - int(cells.min()) <= 2 * 250 * 500
+        rb.sweep()
+        rraw, _, _ = rb.download()
+        assert np.array_equal(rraw.view(np.uint32), eraw.view(np.uint32))
+        rb.release()
+        m.close()
 
 
 def _long_pair(rng, R, H, sub_rate=0.01):

@@ -80,3 +80,46 @@ def test_c_abi_cut_is_the_python_cut():
     which, cells = capi.plan_slices(one, 4, cross=True)  # the region's pair list IS the cross product in (read, hap) order
     which2, cells2 = capi.plan_slices(one, 4)
     assert np.array_equal(which, which2) and np.array_equal(cells, cells2) and int(cells.sum()) == one.cells()
+
+
+@pytest.mark.parametrize("n_slices", [2, 3])
+def test_multi_handle_over_cpu_contexts(n_slices):
+    # phmm_create_multi's whole N > 1 path -- the equal-cells cut, one host thread per slice, per-slice tables holding only what the
+    # slice refers to, the scatter of the results to the pairs' own positions, the common start gate of the timed sweep -- run over
+    # CPU contexts (phmm_create_multi_cpu), against the oracle.  On a GPU box tests/test_gpu_shards.py runs the same with device slices.
+    from rovaca_amd import capi
+    b = synth.make_batch(seed=9, n_regions=12, reads=20, haps=6, read_len=(50, 250), hap_len=(100, 500), sub_rate=0.05)
+    oraw, ol10, oresc = oracle.batch(b, n_threads=8)
+    m = capi.MultiEngine(cpu_slices=n_slices, cpu_threads_each=2)
+    assert m.n_devices == n_slices and m.devices == [-1 - i for i in range(n_slices)]
+    raw, l10, st = m.compute(b)
+    assert np.array_equal(raw.view(np.uint32), oraw.view(np.uint32)) and np.array_equal(l10[~oresc], ol10[~oresc])
+    assert np.abs(l10[oresc] - ol10[oresc]).max() < 1e-9 and int(st.cells) == b.cells() and int(st.n_rescued) == int(oresc.sum()) > 0
+    rb = m.upload(b)
+    cells, pairs = rb.shard_cells()
+    assert int(cells.sum()) == b.cells() and int(pairs.sum()) == b.n_pairs and (pairs > 0).all()
+    assert int(cells.max()) - int(cells.min()) <= 2 * 250 * 500  # each cut within one pair of the ideal
+    which, pcells = capi.plan_slices(b, n_slices)
+    assert [int(c) for c in pcells] == [int(c) for c in cells]
+    rb.sweep()
+    wall, dev, _ = rb.sweep_timed(2)
+    assert (dev > 0).all() and wall >= dev.max() * 0.5 and wall < 50 * dev.max()  # the gate's wall time is the slowest slice's, not a sum of waits
+    rraw, rl10, _ = rb.download()
+    assert np.array_equal(rraw.view(np.uint32), oraw.view(np.uint32)) and np.array_equal(rl10, l10)
+    rb.release()
+    # a shuffled pair list lands every result at its own position again
+    perm = np.random.default_rng(4).permutation(b.n_pairs)
+    praw, _, _ = m.compute(b.subset(perm))
+    assert np.array_equal(praw.view(np.uint32), oraw[perm].view(np.uint32))
+    # the cross-product form and the raw-quality form (read preparation inside every slice) go through the same cut
+    one = synth.make_batch(seed=10, n_regions=1, reads=30, haps=7, read_len=(40, 200), hap_len=(100, 300))
+    craw, _, _ = m.compute(one, cross=True)
+    assert np.array_equal(craw.view(np.uint32), oracle.batch(one, n_threads=4)[0].view(np.uint32))
+    mapq = np.random.default_rng(5).choice(np.array([60, 29, 12], np.uint8), b.n_reads)
+    qraw, _, _ = m.compute(b, prep=(mapq, 18, 3))
+    assert np.array_equal(qraw.view(np.uint32), oracle.batch(oracle.prepare_batch(b, mapq, 18, 3), n_threads=8)[0].view(np.uint32))
+    # more slices than pairs: the surplus slices are empty and harmless
+    tiny = b.subset(np.arange(2))
+    traw, _, _ = m.compute(tiny)
+    assert np.array_equal(traw.view(np.uint32), oraw[:2].view(np.uint32))
+    m.close()
