@@ -15,6 +15,7 @@ extern char **environ;
 namespace phmm_detail
 {
 thread_local int t_hooks = -1;
+thread_local HostPool *t_pool = nullptr;
 bool any_phmm_variable()
 {
     for (char **e = environ; e && *e; ++e)

@@ -4,7 +4,12 @@
 #ifndef ROVACA_AMD_PAIRHMM_BINNING_H_
 #define ROVACA_AMD_PAIRHMM_BINNING_H_
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -75,12 +80,141 @@ static inline uint32_t class_of(uint32_t R, uint32_t H)
 static inline int queue_of_bin(int bin_id, bool queue_per_class) { return bin_id >= 17 ? bin_id - 16 : queue_per_class ? 4 + bin_id : 0; }
 bool queue_per_class_for(uint64_t n_pairs);  // n_pairs > kQueuePerClassMinPairs, or PHMM_FORCE_QUEUE_PER_CLASS (tests)
 
-// Host loops over the pairs of a BIG batch (binning, the final log10) are split over a few threads; a region-sized call
-// never gets here.
+// Host loops over the pairs of a BIG batch (binning, packing, the final log10) are split over a few threads; a region-sized call
+// never gets here.  Two ways to get the threads: a HostPool the calling thread has made current (the chunked one-shot call keeps
+// two in its context: spawning threads for every loop of every chunk cost it ~1 ms per call), or plain std::threads otherwise.
 constexpr uint64_t kParallelMinPairs = 1u << 17;
+
+namespace phmm_detail
+{
+// A few helper threads that take numbered parts of one job at a time.  run() hands out parts [0, parts) to the helpers and to
+// the caller and returns when all are done.  Helpers poll for ~100 us after a job before they sleep: the loops of one call come
+// back to back.
+class HostPool
+{
+public:
+    explicit HostPool(unsigned helpers)
+    {
+        try {
+            for (unsigned i = 0; i < helpers; ++i) threads_.emplace_back([this] { loop(); });
+        }
+        catch (...) {  // (a process out of threads: the caller does the parts itself)
+        }
+    }
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            ++generation_;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    HostPool(const HostPool &) = delete;
+    HostPool &operator=(const HostPool &) = delete;
+    unsigned helpers() const { return (unsigned)threads_.size(); }
+    template <typename F>
+    void run(unsigned parts, F &&fn)  // fn(part index)
+    {
+        if (parts == 0) return;
+        if (parts == 1 || threads_.empty()) {
+            for (unsigned p = 0; p < parts; ++p) fn(p);
+            return;
+        }
+        std::lock_guard<std::mutex> one_job(run_mu_);  // one job at a time (callers that overlap use pools of their own)
+        std::function<void(unsigned)> f = std::ref(fn);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            while (in_job_ != 0) {  // a helper that woke up late for the previous job is still looking at its counters
+                lk.unlock();
+                std::this_thread::yield();
+                lk.lock();
+            }
+            fn_ = &f;
+            parts_ = parts;
+            next_.store(0, std::memory_order_relaxed);
+            done_.store(0, std::memory_order_relaxed);
+            ++generation_;
+            gen_atomic_.store(generation_, std::memory_order_release);
+        }
+        cv_.notify_all();
+        work(f, parts);
+        // the last part may still be running on a helper
+        for (unsigned spins = 0; done_.load(std::memory_order_acquire) != parts; ++spins)
+            if (spins > 2000) std::this_thread::yield();
+        std::lock_guard<std::mutex> lk(mu_);  // no helper is inside this job any more: f may go
+        fn_ = nullptr;
+    }
+
+private:
+    void work(std::function<void(unsigned)> &f, unsigned parts)
+    {
+        for (;;) {
+            const unsigned p = next_.fetch_add(1, std::memory_order_acq_rel);
+            if (p >= parts) return;
+            f(p);
+            done_.fetch_add(1, std::memory_order_acq_rel);
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            // poll briefly for the next job, then sleep
+            const auto t0 = std::chrono::steady_clock::now();
+            bool fresh = false;
+            for (unsigned spins = 0;; ++spins) {
+                if (gen_atomic_.load(std::memory_order_acquire) != seen) {
+                    fresh = true;
+                    break;
+                }
+                if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+            }
+            std::function<void(unsigned)> *f = nullptr;
+            unsigned parts = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (!fresh) cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                f = fn_;
+                parts = parts_;
+                if (f) in_job_ += 1;
+            }
+            if (f) {
+                work(*f, parts);
+                std::lock_guard<std::mutex> lk(mu_);
+                in_job_ -= 1;
+            }
+        }
+    }
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_;
+    std::vector<std::thread> threads_;
+    std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned parts_ = 0, in_job_ = 0;
+    std::atomic<unsigned> next_{0}, done_{0};
+    uint64_t generation_ = 0;
+    std::atomic<uint64_t> gen_atomic_{0};
+    bool stop_ = false;
+};
+extern thread_local HostPool *t_pool;  // the pool parallel_ranges uses on this thread, or null: spawn
+struct PoolScope
+{
+    HostPool *saved;
+    explicit PoolScope(HostPool *p) : saved(t_pool) { t_pool = p; }
+    ~PoolScope() { t_pool = saved; }
+};
+}  // namespace phmm_detail
+
 template <typename F>
 static void parallel_ranges(uint64_t n, unsigned n_threads, F &&fn)  // fn(lo, hi, thread index)
 {
+    if (phmm_detail::HostPool *pool = phmm_detail::t_pool) {
+        pool->run(n_threads, [&](unsigned t) { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
+        return;
+    }
     std::vector<std::thread> th;
     th.reserve(n_threads);
     unsigned started = 1;  // ranges [1, started) run on helper threads; the rest on the caller (a process with 128 workers may

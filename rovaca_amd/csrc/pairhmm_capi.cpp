@@ -146,11 +146,18 @@ void phmm_destroy(phmm_context *c)
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
     }
     delete c->scratch;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < phmm_context::kChunkSlots; ++i) {
         delete c->chunk_slot[i];
         if (c->chunk_up[i]) (void)hipEventDestroy(c->chunk_up[i]);
+        if (c->chunk_swept[i]) (void)hipEventDestroy(c->chunk_swept[i]);
         if (c->chunk_done[i]) (void)hipEventDestroy(c->chunk_done[i]);
     }
+    if (c->down) {
+        (void)hipStreamSynchronize(c->down);
+        (void)hipStreamDestroy(c->down);
+    }
+    delete c->pack_pool;
+    delete c->fin_pool;
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -195,7 +202,8 @@ static thread_local PhaseClock *g_phase = nullptr;
 // indices still counted from the start of the caller's tables.
 struct UploadOpts
 {
-    hipStream_t stream = nullptr;  // null: the context's stream
+    hipStream_t stream = nullptr;  // the copy; null: the context's stream
+    hipStream_t setup_stream = nullptr;  // the fill and the set-up launch; null: the stream of the copy
     bool caller_synchronised = false;  // the caller knows that nothing on the device still reads this resident's buffers
     uint32_t read_bias = 0, hap_bias = 0;  // subtracted from pair_read / pair_hap
 };
@@ -356,7 +364,18 @@ static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, 
     PHASE(2);
 
     // ---- upload ----
-    if (total) HIP_TRY(hipMemcpyAsync(rb->blob.p, rb->stage.p, total, hipMemcpyHostToDevice, st));
+    if (opt.setup_stream && opt.setup_stream != st) {
+        // The chunked call: the set-up launch goes on the sweep stream and must see the copy.  A device-side wait there
+        // (hipStreamWaitEvent) cost ~50 us of idle queue at every chunk boundary, and an event behind an asynchronous copy on the
+        // upload stream does not fire before the sweep that is running has drained (its marker sits in a compute queue the busy
+        // chip does not get round to: measured, hipEventSynchronize returned 1.7 ms late).  A synchronous copy waits on the DMA
+        // engine's own signal: the calling thread is a chunk ahead of the device and has nothing else to do meanwhile.
+        if (total) HIP_TRY(hipMemcpy(rb->blob.p, rb->stage.p, total, hipMemcpyHostToDevice));
+        st = opt.setup_stream;
+    }
+    else if (total) {
+        HIP_TRY(hipMemcpyAsync(rb->blob.p, rb->stage.p, total, hipMemcpyHostToDevice, st));
+    }
     uint8_t *base = rb->blob.p;
     rb->read_bases = {base + o_bases, (size_t)read_bytes};
     rb->read_qual = {base + o_qual, (size_t)read_bytes};
@@ -928,7 +947,7 @@ struct ChunkWindow
 };
 
 constexpr uint64_t kChunkedMinPairs = 1u << 19;  // below this one upload + one sweep is as fast
-constexpr uint64_t kChunkTargetPairs = 1u << 18;
+constexpr uint64_t kChunkTargetPairs = 1u << 17;
 constexpr unsigned kMaxChunks = 8;
 
 // Cuts the pair list into contiguous chunks and finds each chunk's table windows.  Returns false when chunking would not
@@ -942,11 +961,18 @@ static bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
     if (const char *e = phmm_hook("PHMM_NO_CHUNKED_COMPUTE")) {  // tests
         if (e[0] != '0') return false;
     }
-    // Chunk sizes rise and fall (1 : 2 : 3 : 3 : 2 : 1): the first chunk's packing and the last chunk's host log10 are the
-    // only host work the device cannot hide, so those two chunks are the small ones.
+    // Chunk sizes rise and fall: the first chunk's packing and the last chunk's conversion are the only host work the device
+    // cannot hide, so those two are small -- 2 % and 8 % of the batch from seven chunks on.
     unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(2, n / kChunkTargetPairs + 2));
     std::vector<unsigned> weight(C);
     for (unsigned k = 0; k < C; ++k) weight[k] = std::min(k + 1, std::min(C - k, 3u));
+    if (C >= 7) {
+        // percent of the batch.  Packing is ~2.6x faster than sweeping, so a chunk may be up to 2.6x the one before it without the
+        // device running dry; the first is as small as a launch can usefully be, the last small enough for a short conversion tail
+        static const unsigned graded[] = {2, 6, 14, 26, 26, 18, 8};
+        C = 7;
+        weight.assign(graded, graded + 7);
+    }
     if (const char *e = phmm_hook("PHMM_CHUNK_WEIGHTS")) {  // tuning aid: relative chunk sizes, e.g. "1,2,3,2,1"
         std::vector<unsigned> w;
         for (const char *q = e; *q;) {
@@ -1034,88 +1060,167 @@ static bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
     return win_bytes <= once + once / 2 + (1u << 20);
 }
 
+// The chunked one-shot call as a two-thread pipeline.  The calling thread bins, packs and enqueues chunk after chunk without ever
+// waiting for the device (upload + set-up on the upload stream, the sweep behind an event on the context's stream, the result
+// copy behind another event on the download stream, so that the next sweep starts the moment this one ends); a collector thread
+// takes the chunks in order as their results arrive, fetches the fp64 sums where anything was rescued, and does the host log10.
+// Three resident slots: chunk k is packed while k - 1 is swept and k - 2 is being converted.  The device queue stays non-empty
+// from the first chunk's sweep to the last one's -- round 2 packed chunk k + 1 only after chunk k - 1 had been collected, and the
+// sweeps of one call took 10.0 ms for 8.3 ms of work because the clock ramped down in the gaps.
 static int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<ChunkWindow> &plan, float *out_raw_f32,
                            double *out_log10, phmm_stats *stats)
 {
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < 2; ++i) {
+    constexpr int S = phmm_context::kChunkSlots;
+    for (int i = 0; i < S; ++i) {
         if (!c->chunk_slot[i]) {
             c->chunk_slot[i] = new (std::nothrow) phmm_resident();
             if (!c->chunk_slot[i]) return fail(PHMM_E_NOMEM, "phmm_compute: out of host memory");
         }
         if (!c->chunk_up[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_up[i], hipEventDisableTiming));
+        if (!c->chunk_swept[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_swept[i], hipEventDisableTiming));
         if (!c->chunk_done[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming));
     }
+    if (!c->down) HIP_TRY(hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking));
     hipStream_t up = c->side[phmm_context::kSideStreams - 1];  // not used by the sweeps (n_side defaults to 2 of 3)
-    const bool sweeps_use_it = c->n_side >= phmm_context::kSideStreams;
-    if (sweeps_use_it) up = c->stream;
+    if (c->n_side >= phmm_context::kSideStreams) up = c->stream;
+    hipStream_t down = c->down;
     HIP_TRY(hipStreamSynchronize(c->stream));  // nothing of an earlier call still reads the slots
     if (up != c->stream) HIP_TRY(hipStreamSynchronize(up));
+    HIP_TRY(hipStreamSynchronize(down));
     const bool cross = b->pair_read == nullptr;
-    phmm_stats total{};
-    std::vector<uint32_t> roff, hoff;
+    const size_t n_chunks = plan.size();
+    const bool trace = getenv("PHMM_PHASE_TIMING") != nullptr;  // tuning aid: host time line of the pipeline on stderr
+    const bool direct = phmm_hook("PHMM_CHUNK_RESULTS_BY_COPY") == nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+
     struct InFlight
     {
         const ChunkWindow *w = nullptr;
         size_t count_at = 0;
-    } fl[2];
+    } fl[S];
+    // hand-off between the two threads: chunks [0, enqueued) are on the device, [0, collected) are finished
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t enqueued = 0, collected = 0;
+    bool producer_failed = false;
+    int collector_rc = PHMM_OK;
+    std::string collector_msg;
+    phmm_stats total{};
 
-    // results of chunk `slot` (its sums and rescue counts are on their way to the slot's pinned staging): wait, fetch the
-    // fp64 sums if anything was rescued, finalise on the host (pairhmm_internal.cpp:577-585)
-    auto collect = [&](int slot) -> int {
+    auto collect = [&](size_t k) -> int {
+        const int slot = (int)(k % S);
         phmm_resident *rb = c->chunk_slot[slot];
         const ChunkWindow &w = *fl[slot].w;
         const uint64_t n = rb->n_pairs;
         HIP_TRY(hipEventSynchronize(c->chunk_done[slot]));
+        const double t_ready = trace ? now_us() : 0.0;
         const size_t off_cnt = fl[slot].count_at * sizeof(float), off64 = off_cnt + 256;
         const uint8_t *st = static_cast<const uint8_t *>(rb->out_stage.p);
-        const uint32_t *counts = reinterpret_cast<const uint32_t *>(st + off_cnt);
-        rb->last_rescued = 0;
-        for (int qi = 0; qi < kQueues; ++qi) rb->last_rescued += counts[qi];
-        const bool want64 = out_log10 && rb->last_rescued;
-        if (want64) {
-            // the rescue kernels of this chunk are done (the event above follows them); the copy runs beside the next sweep
-            HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(st) + off64, rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, up));
-            HIP_TRY(hipStreamSynchronize(up));
-        }
         const float *rp = reinterpret_cast<const float *>(st);
         const double *r64 = reinterpret_cast<const double *>(st + off64);
+        bool want64 = true;  // results written by the kernels straight into the pinned stage: the fp64 sums are there already
+        if (!direct) {
+            const uint32_t *counts = reinterpret_cast<const uint32_t *>(st + off_cnt);
+            rb->last_rescued = 0;
+            for (int qi = 0; qi < kQueues; ++qi) rb->last_rescued += counts[qi];
+            want64 = out_log10 && rb->last_rescued;
+            if (want64) {
+                // the rescue kernels of this chunk are done (the event above follows them); the copy runs beside the next sweep
+                HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(st) + off64, rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, down));
+                HIP_TRY(hipStreamSynchronize(down));
+            }
+        }
         if (out_raw_f32) memcpy(out_raw_f32 + w.p0, rp, n * sizeof(float));
-        if (out_log10) {
-            double *dst = out_log10 + w.p0;
-            auto finalize = [&](uint64_t lo, uint64_t hi, unsigned) {
+        std::atomic<uint64_t> n_resc{0};
+        {
+            double *dst = out_log10 ? out_log10 + w.p0 : nullptr;
+            auto finalize = [&](uint64_t lo, uint64_t hi, unsigned) {  // pairhmm_internal.cpp:577-585
+                uint64_t resc = 0;
                 for (uint64_t p = lo; p < hi; ++p) {
                     const float x = rp[p];
-                    if (x < PHMM_MIN_ACCEPTED_F32)
-                        dst[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
-                    else
+                    if (x < PHMM_MIN_ACCEPTED_F32) {
+                        ++resc;
+                        if (dst) dst[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
+                    }
+                    else if (dst) {
                         dst[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
+                    }
                 }
+                n_resc.fetch_add(resc, std::memory_order_relaxed);
             };
-            if (n >= kParallelMinPairs)
-                parallel_ranges(n, std::min(4u, host_threads()), finalize);
+            if (n >= (1u << 14))
+                parallel_ranges(n, c->fin_pool->helpers() + 1u, finalize);
             else
                 finalize(0, n, 0);
         }
+        rb->last_rescued = (uint32_t)n_resc.load();
         total.cells += rb->cells;
         total.n_rescued += rb->last_rescued;
         total.n_launches += (uint32_t)rb->bins.size();
         if (!rb->bins.empty()) total.max_rows_per_lane = std::max<uint32_t>(total.max_rows_per_lane, (uint32_t)rb->bins.back().rows_per_lane);
+        if (trace) fprintf(stderr, "phmm chunk %zu: results on the host at %.0f us, converted at %.0f us\n", k, t_ready, now_us());
         return PHMM_OK;
     };
 
-    const bool trace = getenv("PHMM_PHASE_TIMING") != nullptr;  // tuning aid: host time line of the pipeline on stderr
-    PhaseClock clock;
-    struct PhaseScope
+    std::thread collector([&] {
+        (void)hipSetDevice(c->device);
+        phmm_detail::PoolScope pool(c->fin_pool);
+        for (size_t k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return enqueued > k || producer_failed; });
+                if (enqueued <= k) return;  // the producer gave up before this chunk
+            }
+            int rc = PHMM_OK;
+            try {
+                rc = collect(k);
+            }
+            catch (...) {
+                rc = fail(PHMM_E_NOMEM, "phmm_compute: the collector thread ran out of memory");
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc != PHMM_OK && collector_rc == PHMM_OK) {
+                    collector_rc = rc;
+                    collector_msg = g_err;  // (thread-local: carry the text over)
+                }
+                collected = k + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    struct Joiner  // whichever way this function returns, the collector is told and joined first
     {
-        explicit PhaseScope(PhaseClock *p) { g_phase = p; }
-        ~PhaseScope() { g_phase = nullptr; }
-    } phase_scope(trace ? &clock : nullptr);
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
-    for (size_t k = 0; k < plan.size(); ++k) {
+        std::thread &t;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &failed;
+        bool ok = false;
+        ~Joiner()
+        {
+            if (!ok) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    failed = true;
+                }
+                cv.notify_all();
+            }
+            t.join();
+        }
+    } joiner{collector, mu, cv, producer_failed};
+
+    phmm_detail::PoolScope pool(c->pack_pool);
+    std::vector<uint32_t> roff, hoff;
+    for (size_t k = 0; k < n_chunks; ++k) {
         const ChunkWindow &w = plan[k];
-        const int slot = (int)(k & 1);
+        const int slot = (int)(k % S);
+        if (k >= (size_t)S) {  // the slot held chunk k - S: its results must have left it
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return collected + S > k; });
+            if (collector_rc != PHMM_OK) break;
+        }
         const double t_a = trace ? now_us() : 0.0;
         phmm_resident *rb = c->chunk_slot[slot];
         // the chunk as a batch of its own: windows of the tables, offsets rebased to the windows, pair indices biased
@@ -1147,40 +1252,65 @@ static int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vect
         }
         UploadOpts opt;
         opt.stream = up;
-        opt.caller_synchronised = true;  // slot `slot` held chunk k - 2, collected during the last iteration
+        opt.caller_synchronised = true;  // slot `slot` held chunk k - S: collected (see above), so its sweep is long over
         opt.read_bias = cross ? 0 : w.r0;
         opt.hap_bias = cross ? 0 : w.h0;
+        // The copy travels on the upload stream (DMA engines: it runs beside the previous chunk's sweep); the set-up launch goes on
+        // the context's stream, in front of this chunk's sweep.  On the upload stream it would not start before the previous sweep
+        // has handed out its last workgroup -- small kernels of another queue are starved by a grid that fills the chip -- and the
+        // sweep behind it would wait with it: 90-110 us of a drained chip at every chunk boundary (rocprofv3 time line, round 3).
+        opt.setup_stream = c->stream;
+        if (k == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        PhaseClock chunk_clock;
+        struct PhaseScope
+        {
+            explicit PhaseScope(PhaseClock *p) { g_phase = p; }
+            ~PhaseScope() { g_phase = nullptr; }
+        } phase_scope(trace ? &chunk_clock : nullptr);
         int rc = upload_into(c, &s, rb, opt);
         if (rc != PHMM_OK) return rc;
-        if (up != c->stream) {
-            HIP_TRY(hipEventRecord(c->chunk_up[slot], up));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->chunk_up[slot], 0));
-        }
-        if (k == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-        rc = impl::phmm_sweep(c, rb);
-        if (rc != PHMM_OK) return rc;
-        if (k + 1 == plan.size()) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        // where the sums go: straight into the slot's pinned result block (the kernels write host memory over PCIe: no copy, no
+        // cross-stream event between two sweeps), or -- PHMM_CHUNK_RESULTS_BY_COPY=1 -- into HBM and from there by a copy
         const uint64_t n = rb->n_pairs;
         const size_t count_at = (n + 63) & ~size_t(63);
         HIP_TRY(rb->out_stage.ensure(count_at * sizeof(float) + 256 + n * sizeof(double)));
-        HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, count_at * sizeof(float) + kQueues * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipEventRecord(c->chunk_done[slot], c->stream));
+        rb->out32_host = direct ? static_cast<float *>(rb->out_stage.p) : nullptr;
+        rb->out64_host = direct ? reinterpret_cast<double *>(static_cast<uint8_t *>(rb->out_stage.p) + count_at * sizeof(float) + 256) : nullptr;
+        rc = impl::phmm_sweep(c, rb);
+        if (rc != PHMM_OK) return rc;
+        PHASE(4);
+        if (k + 1 == n_chunks) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        if (direct) {
+            HIP_TRY(hipEventRecord(c->chunk_done[slot], c->stream));
+        }
+        else {
+            // the sums travel on the download stream: the next chunk's sweep does not queue behind the copy
+            HIP_TRY(hipEventRecord(c->chunk_swept[slot], c->stream));
+            HIP_TRY(hipStreamWaitEvent(down, c->chunk_swept[slot], 0));
+            HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, count_at * sizeof(float) + kQueues * sizeof(uint32_t), hipMemcpyDeviceToHost, down));
+            HIP_TRY(hipEventRecord(c->chunk_done[slot], down));
+        }
         fl[slot].w = &w;
         fl[slot].count_at = count_at;
-        const double t_b = trace ? now_us() : 0.0;
-        if (k > 0) {
-            rc = collect((int)((k - 1) & 1));  // the GPU sweeps chunk k meanwhile
-            if (rc != PHMM_OK) return rc;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            enqueued = k + 1;
         }
-        if (trace)
-            fprintf(stderr, "phmm chunk %zu: %llu pairs, pack+enqueue %.0f..%.0f us, previous chunk collected at %.0f us\n", k,
-                    (unsigned long long)(w.p1 - w.p0), t_a, t_b, now_us());
+        cv.notify_all();
+        if (trace) {
+            PHASE(5);
+            fprintf(stderr, "phmm chunk %zu: %llu pairs, packed and enqueued %.0f..%.0f us (validate %.0f pack %.0f bin %.0f copy+setup %.0f sweep-enqueue %.0f results-enqueue %.0f)\n",
+                    k, (unsigned long long)(w.p1 - w.p0), t_a, now_us(), chunk_clock.us[0], chunk_clock.us[1], chunk_clock.us[2], chunk_clock.us[3],
+                    chunk_clock.us[4], chunk_clock.us[5]);
+        }
     }
-    int rc = collect((int)((plan.size() - 1) & 1));
-    if (rc != PHMM_OK) return rc;
-    if (trace)
-        fprintf(stderr, "phmm chunked phases us (summed over chunks): validate %.1f pack %.1f bin %.1f enqueue-upload %.1f\n", clock.us[0],
-                clock.us[1], clock.us[2], clock.us[3]);
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return collected >= enqueued || collector_rc != PHMM_OK; });
+    }
+    joiner.ok = enqueued == n_chunks;
+    if (collector_rc != PHMM_OK) return fail(collector_rc, "%s", collector_msg.c_str());
+    if (enqueued != n_chunks) return fail(PHMM_E_INVALID, "phmm_compute: the chunk pipeline stopped early");
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -1207,6 +1337,12 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
     }
     {
         std::vector<ChunkWindow> plan;
+        const uint64_t n_all = b->pair_read ? b->n_pairs : (uint64_t)b->n_reads * b->n_haps;
+        if (n_all >= kChunkedMinPairs) {  // the helper threads of the chunk pipeline (also used by the plan itself)
+            if (!c->pack_pool) c->pack_pool = new phmm_detail::HostPool(std::max(1u, host_threads()) - 1u);
+            if (!c->fin_pool) c->fin_pool = new phmm_detail::HostPool(3);
+        }
+        phmm_detail::PoolScope pool(n_all >= kChunkedMinPairs ? c->pack_pool : nullptr);
         const bool tables_ok = b->read_bases && b->read_qual && b->read_off && b->read_len && b->hap_bases && b->hap_off && b->hap_len &&
                                ((b->pair_read == nullptr) == (b->pair_hap == nullptr)) && (b->prep ? b->prep->read_mapq != nullptr : true);
         if (tables_ok && plan_chunks(b, plan)) {

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -123,10 +124,15 @@ struct phmm_context
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
     struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
-    // big one-shot batches are cut into chunks that alternate between two resident slots: chunk k + 1 is binned, packed and
-    // uploaded (on side[2]) while chunk k is swept, chunk k - 1 finalised on the host meanwhile
-    struct phmm_resident *chunk_slot[2] = {nullptr, nullptr};
-    hipEvent_t chunk_up[2] = {nullptr, nullptr}, chunk_done[2] = {nullptr, nullptr};
+    // big one-shot batches are cut into chunks that go round three resident slots: chunk k is binned, packed and uploaded (on
+    // side[2]) while chunk k - 1 is swept and chunk k - 2 is converted on the host by a collector thread (pairhmm_capi.cpp:
+    // compute_chunked); the sums come back on a stream of their own so that the next sweep does not queue behind the copy
+    static constexpr int kChunkSlots = 3;
+    struct phmm_resident *chunk_slot[kChunkSlots] = {nullptr, nullptr, nullptr};
+    hipEvent_t chunk_up[kChunkSlots] = {nullptr, nullptr, nullptr}, chunk_swept[kChunkSlots] = {nullptr, nullptr, nullptr},
+               chunk_done[kChunkSlots] = {nullptr, nullptr, nullptr};
+    hipStream_t down = nullptr;  // result copies of the chunked call
+    phmm_detail::HostPool *pack_pool = nullptr, *fin_pool = nullptr;  // helper threads of the two sides of that pipeline
     phmm_detail::BinScratch bin_scratch;       // host scratch of the length binning, kept between calls
     std::vector<hipEvent_t> timing;            // event pool of phmm_sweep_timed
     struct phmm_stage *region_stage = nullptr; // phmm_compute_regions: the stage host buffers are copied into (pairhmm_stage.cpp)

@@ -17,34 +17,34 @@ namespace phmm
 //   plane 5   : read symbol outside ACGTN: never matches (all zero)
 // Words past the haplotype end are zero.
 // ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void hap_planes_word(const uint8_t *__restrict__ hap_bases, const uint32_t *__restrict__ hap_off,
-                                                const uint32_t *__restrict__ hap_len, const uint32_t *__restrict__ plane_off,
-                                                const uint32_t *__restrict__ word_owner, uint32_t n_words,
-                                                uint32_t *__restrict__ planes, uint32_t g)
+// A wave builds TWO global word slots at a time (one column per lane, one ballot per plane); the two may belong to different
+// haplotypes.  (Until round 3 one thread built one word from 32 dependent byte loads: 24-29 us per launch whatever its size.)
+__device__ __forceinline__ void hap_planes_words2(const uint8_t *__restrict__ hap_bases, const uint32_t *__restrict__ hap_off,
+                                                  const uint32_t *__restrict__ hap_len, const uint32_t *__restrict__ plane_off,
+                                                  const uint32_t *__restrict__ word_owner, uint32_t n_words,
+                                                  uint32_t *__restrict__ planes, uint32_t g0)
 {
-    if (g >= n_words) return;
+    if (g0 >= n_words) return;  // wave-uniform
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g = g0 + (lane >> 5);  // this half-wave's word slot
+    const bool live = g < n_words;
     // word_owner[g] = haplotype that owns global word slot g; the slot index inside that haplotype follows
-    uint32_t h = word_owner[g];
-    uint32_t H = hap_len[h];
-    uint32_t W = planes_words(H);
-    uint32_t w = g - (plane_off[h] / kPlanes);  // plane_off is in words and counts kPlanes * W per haplotype
-    const uint8_t *hb = hap_bases + hap_off[h];
-    uint32_t bits[kPlanes] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t b = 0; b < 32; ++b) {
-        uint32_t j0 = w * 32 + b;
-        if (j0 < H) {
-            uint8_t c = hb[j0];
-            uint32_t bit = 0x80000000u >> b;
-            bool isN = c == 'N';
-            if (c == 'A' || isN) bits[0] |= bit;
-            if (c == 'C' || isN) bits[1] |= bit;
-            if (c == 'G' || isN) bits[2] |= bit;
-            if (c == 'T' || isN) bits[3] |= bit;
-            if (c == 'A' || c == 'C' || c == 'G' || c == 'T' || isN) bits[4] |= bit;
-        }
+    const uint32_t h = word_owner[live ? g : g0];
+    const uint32_t H = hap_len[h], W = planes_words(H), po = plane_off[h];
+    const uint32_t w = g - po / kPlanes;  // plane_off is in words and counts kPlanes * W per haplotype
+    const uint32_t j0 = w * 32u + (lane & 31u);
+    const uint8_t c = live && j0 < H ? hap_bases[hap_off[h] + j0] : (uint8_t)0;  // 0 matches nothing
+    const bool isN = c == 'N';
+    const bool m[kPlanes - 1] = {c == 'A' || isN, c == 'C' || isN, c == 'G' || isN, c == 'T' || isN,
+                                 c == 'A' || c == 'C' || c == 'G' || c == 'T' || isN};
+    uint32_t *dst = planes + po;
+#pragma unroll
+    for (int p = 0; p < kPlanes - 1; ++p) {
+        const uint64_t b = __ballot(m[p]);  // lane i -> bit i; a plane word wants column 32 w + k at bit 31 - k
+        const uint32_t mine = __brev((lane >> 5) ? (uint32_t)(b >> 32) : (uint32_t)b);
+        if (live && (lane & 31u) == 0) dst[p * W + w] = mine;
     }
-    uint32_t *dst = planes + plane_off[h];
-    for (int c = 0; c < kPlanes; ++c) dst[c * W + w] = bits[c];
+    if (live && (lane & 31u) == 0) dst[(kPlanes - 1) * W + w] = 0;  // plane 5: a read symbol outside ACGTN never matches
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -225,7 +225,7 @@ __device__ __forceinline__ void prep_one_read(const uint8_t *__restrict__ read_b
 }
 
 // One launch sets a batch up: workgroups [0, n_prep_reads) prepare one read each (H3 + H4, only for batches that carry a
-// phmm_read_prep), the rest build the haplotype bit planes, one thread per 32-column word; the rescue queue is emptied on
+// phmm_read_prep), the rest build the haplotype bit planes, one wave per two 32-column words; the rescue queue is emptied on
 // the way.  A region-sized call is a chain of dependent launches and copies, each worth 5-10 us: fewer links, lower latency.
 __global__ void __launch_bounds__(kSetupThreads) setup_kernel(SetupArgs s)
 {
@@ -237,13 +237,14 @@ __global__ void __launch_bounds__(kSetupThreads) setup_kernel(SetupArgs s)
                       s.gap_open, s.gap_cont, blockIdx.x, sb, masks);
         return;
     }
-    hap_planes_word(s.hap_bases, s.hap_off, s.hap_len, s.plane_off, s.word_owner, s.n_words, s.planes,
-                    (blockIdx.x - s.n_prep_reads) * kSetupThreads + threadIdx.x);
+    hap_planes_words2(s.hap_bases, s.hap_off, s.hap_len, s.plane_off, s.word_owner, s.n_words, s.planes,
+                      ((blockIdx.x - s.n_prep_reads) * (kSetupThreads / 64) + (threadIdx.x >> 6)) * 2u);
 }
 
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
 {
-    const uint32_t blocks = a.n_prep_reads + (a.n_words + kSetupThreads - 1) / kSetupThreads;
+    const uint32_t words_per_block = 2u * (kSetupThreads / 64);  // two word slots per wave
+    const uint32_t blocks = a.n_prep_reads + (a.n_words + words_per_block - 1) / words_per_block;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(setup_kernel, dim3(blocks), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
