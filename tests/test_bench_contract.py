@@ -46,3 +46,19 @@ def test_device_line_has_roofline_and_cpu_baseline():
     assert "error" not in ad, ad
     assert ad["bit_identical_to_resident_path"] is True and ad["value"] > 0 and ad["synchronous_seam"]["value"] > 0
     assert ad["workers"] >= 1 and ad["regions_per_submission"] >= 1.0 and ad["regions"] == ad["workers"] * 2000
+
+
+def test_committed_pmc_counters_belong_to_the_committed_kernels():
+    # profiles/hbm_traffic.json feeds roofline.traffic and roofline_issue on the bench line: it must have been collected from the
+    # kernel sources in the tree (tools/profile_round.sh + tools/summarize_profiles.py after the last kernel change)
+    from rovaca_amd import kernel_source_id
+    pj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert pj.get("kernel_source_id") == kernel_source_id(), "stale PMC counters: re-run tools/profile_round.sh on the GPU box and tools/summarize_profiles.py"
+    assert pj["c2"] > 0 and pj["c2_valu_wave_instructions"] > 0 and "pairhmm_systolic" in pj["c2_kernel"]
+
+
+@pytest.mark.gpu
+def test_device_line_carries_the_measured_traffic():
+    d = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-adapter")
+    assert d["roofline"]["traffic"] and d["roofline"]["traffic"] < d["roofline"]["algorithmic_bytes"]  # reads shared 25x / 40x inside the L2s
+    assert 0.5 < d["roofline_issue"]["frac"] <= 1.0

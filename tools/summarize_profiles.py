@@ -26,14 +26,22 @@ m = re.search(r'"kernel_ms": ([0-9.]+)', open(os.path.join(src, "bench_c2.log"))
 if m:
     bench_ms = float(m.group(1))
 
-counters = {}
-for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        if "pairhmm_systolic" not in r["Kernel_Name"]:
-            continue
-        counters.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
-        counters[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-mean = {k: sum(v.values()) / len(v) for k, v in counters.items()}
+def collect(pattern, kernel_substring):
+    """mean per launch of every counter over the PMC passes matching `pattern`, and the kernel's name"""
+    counters, name = {}, None
+    for f in glob.glob(os.path.join(src, pattern, "pmc_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kernel_substring not in r["Kernel_Name"]:
+                continue
+            name = r["Kernel_Name"]
+            counters.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            counters[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return counters, {k: sum(v.values()) / len(v) for k, v in counters.items()}, name
+
+
+counters, mean, _ = collect("pmc_*", "pairhmm_systolic")
+# the same batch through the general kernel (per-base gap-opens, what a run under the default PCR model takes): PHMM_NO_UNIFORM_GOP=1 passes
+_, mean_pcr, pcr_kernel = collect("pmcpcr_*", "pairhmm_systolic")
 avg_ms = float(hot["AverageNs"]) / 1e6
 lines = [
     "rocprofv3 --pmc passes (separate runs, one counter group each; tools/profile_round.sh) of",
@@ -57,8 +65,15 @@ if "SQ_INSTS_VALU" in mean and "SQ_WAVES" in mean:
                      % (ghz, avg_ms, avg_ms * 1e-3 * ghz * 1e9 * 1024 / mean["SQ_INSTS_VALU"]))
 open(os.path.join(dst, "%s_c2_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
 if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+    sys.path.insert(0, ROOT)
+    from rovaca_amd import kernel_source_id
     fetch, write = mean["FETCH_SIZE"] * 1024, mean["WRITE_SIZE"] * 1024
-    json.dump({"c2": int(2 * fetch + write),
+    extra = {}
+    if mean_pcr.get("FETCH_SIZE") and mean_pcr.get("WRITE_SIZE"):
+        extra = {"c2_pcr": int(2 * mean_pcr["FETCH_SIZE"] * 1024 + mean_pcr["WRITE_SIZE"] * 1024),
+                 "c2_pcr_valu_wave_instructions": int(mean_pcr.get("SQ_INSTS_VALU", 0)),
+                 "c2_pcr_kernel": (pcr_kernel or "").replace("void ", "").split("(")[0]}
+    json.dump({"kernel_source_id": kernel_source_id(), **extra, "c2": int(2 * fetch + write),
                "_note": "bytes per launch of %s on config c2: 2 x FETCH_SIZE (gfx950 correction, upper bound) + WRITE_SIZE, "
                         "from profiles/%s_c2_pmc_summary.txt" % (hot["Name"].replace("void ", "").split("(")[0], tag),
                "c2_fetch_raw_bytes": int(fetch), "c2_write_bytes": int(write),
