@@ -314,26 +314,80 @@ void sw_hip_batching_stats(uint64_t *requests, uint64_t *submissions)
 
 extern "C" {
 
-void sw_hip_run(p_lib_sw_avx p)
+// what sw_avx512_run leaves in the handle (sw_avx.c:488-500), from one alignment of a batch
+static void store_alignment(p_lib_sw_avx p, const rovaca::SwAlignment &a)
+{
+    p->score = a.score;
+    p->max_i = a.max_i;
+    p->max_j = a.max_j;
+    p->alignment_offset = a.alignment_offset;
+    // sw_avx.c:349-358 keeps an element only while cur_size + 1 < cigar_max_len: at most cigar_max_len - 1 of them
+    uint32_t count = (uint32_t)a.cigar.size();
+    const uint32_t keep = p->cigar_max_len > 0 ? p->cigar_max_len - 1 : 0;
+    if (count > keep) count = keep;
+    memcpy(p->cigar, a.cigar.data(), count * sizeof(uint32_t));
+    p->cigar_count = count;
+}
+static bool too_long_for(p_lib_sw_avx p)
 {
     const int len = p->len1 > p->len2 ? p->len1 : p->len2;
-    if (len >= p->max_seq_len || len >= SWHIP_MAX_SEQ_LEN) {  // sw_avx.c:490-495
+    return len >= p->max_seq_len || len >= SWHIP_MAX_SEQ_LEN;  // sw_avx.c:490-495
+}
+
+void sw_hip_run(p_lib_sw_avx p)
+{
+    if (too_long_for(p)) {
         p->alignment_offset = 1;
         return;
     }
     const rovaca::SwJob job{p->seq1, p->len1, p->seq2, p->len2};
     std::vector<rovaca::SwAlignment> out;
     if (!rovaca::sw_hip_align_batch(&job, 1, p->para, out)) exit(EXIT_FAILURE);
-    p->score = out[0].score;
-    p->max_i = out[0].max_i;
-    p->max_j = out[0].max_j;
-    p->alignment_offset = out[0].alignment_offset;
-    // sw_avx.c:349-358 keeps an element only while cur_size + 1 < cigar_max_len: at most cigar_max_len - 1 of them
-    uint32_t count = (uint32_t)out[0].cigar.size();
-    const uint32_t keep = p->cigar_max_len > 0 ? p->cigar_max_len - 1 : 0;
-    if (count > keep) count = keep;
-    memcpy(p->cigar, out[0].cigar.data(), count * sizeof(uint32_t));
-    p->cigar_count = count;
+    store_alignment(p, out[0]);
+}
+
+// Every handle as sw_hip_run would leave it, in ONE device call per parameter set: the C entry for a caller that has several
+// alignments at hand -- the assembler aligns every haplotype path of a region to the padded reference one call at a time
+// (apply/assemble/hc_assemble_cigar_cacl.c:417-428; INTEGRATION.md has the patch that collects a region's paths first).  Each
+// handle carries its own sequences, parameters and CIGAR buffer.  Returns 0; a device failure logs to stderr and returns 1 with
+// no handle written.
+int sw_hip_align_many(p_lib_sw_avx *handles, size_t n)
+{
+    if (n == 0) return 0;
+    if (!handles) return 1;
+    std::vector<size_t> todo;
+    todo.reserve(n);
+    for (size_t k = 0; k < n; ++k) {
+        if (!handles[k]) return 1;
+        if (!too_long_for(handles[k])) todo.push_back(k);
+    }
+    std::vector<char> taken(todo.size(), 0);
+    std::vector<std::vector<rovaca::SwAlignment>> results;
+    std::vector<std::vector<size_t>> groups;
+    for (size_t i = 0; i < todo.size(); ++i) {
+        if (taken[i]) continue;
+        const sw_parameters para = handles[todo[i]]->para;  // one device call per distinct parameter set (two in the reference: sw_avx.c:13-14)
+        std::vector<size_t> group;
+        std::vector<rovaca::SwJob> jobs;
+        for (size_t j = i; j < todo.size(); ++j) {
+            p_lib_sw_avx q = handles[todo[j]];
+            if (taken[j] || q->para.match != para.match || q->para.mismatch != para.mismatch || q->para.gap_open != para.gap_open ||
+                q->para.gap_extend != para.gap_extend)
+                continue;
+            taken[j] = 1;
+            group.push_back(todo[j]);
+            jobs.push_back(rovaca::SwJob{q->seq1, q->len1, q->seq2, q->len2});
+        }
+        std::vector<rovaca::SwAlignment> out;
+        if (!rovaca::sw_hip_align_batch(jobs.data(), jobs.size(), para, out)) return 1;
+        results.push_back(std::move(out));
+        groups.push_back(std::move(group));
+    }
+    for (size_t k = 0; k < n; ++k)
+        if (too_long_for(handles[k])) handles[k]->alignment_offset = 1;
+    for (size_t g = 0; g < groups.size(); ++g)
+        for (size_t i = 0; i < groups[g].size(); ++i) store_alignment(handles[groups[g][i]], results[g][i]);
+    return 0;
 }
 
 void sw_hip_set_device(int device_id) { g_sw_device.store(device_id); }
@@ -397,6 +451,54 @@ int rovaca_amd_sw_run_through_handle(const uint8_t *seq1, int32_t len1, const ui
     for (uint32_t k = 0; k < p->cigar_count && k < cigar_cap; ++k) cigar[k] = p->cigar[k];
     free(p);
     return 0;
+}
+
+// Test shim for sw_hip_align_many: n handles laid out as sw_avx_init does, alternating parameter sets when mixed != 0, filled like
+// hc_assemle_cigar_cacl_run_sw fills its one handle; results[k] = {score, max_i, max_j, alignment_offset, cigar_count}, the CIGAR of
+// alignment k at cigars[cigar_at[k] ..).  Returns what sw_hip_align_many returned, -1 when no device, -2 out of memory.
+int rovaca_amd_sw_many_through_handles(const uint8_t *ref_bytes, const uint32_t *ref_off, const uint32_t *ref_len, const uint8_t *seq_bytes,
+                                       const uint32_t *seq_off, const uint32_t *seq_len, uint32_t n, int is_assemble, int mixed, int32_t *result,
+                                       uint32_t *cigars, const uint32_t *cigar_at)
+{
+    const uint32_t max_seq = SWHIP_MAX_SEQ_LEN;
+    const size_t bytes = sizeof(lib_sw_avx) + 2 * (size_t)max_seq + max_seq * sizeof(uint32_t);
+    std::vector<p_lib_sw_avx> h(n, nullptr);
+    int rc = 0;
+    for (uint32_t k = 0; k < n && rc == 0; ++k) {
+        p_lib_sw_avx p = (p_lib_sw_avx)calloc(1, bytes);
+        if (!p) {
+            rc = -2;
+            break;
+        }
+        h[k] = p;
+        p->max_seq_len = (int32_t)max_seq;
+        p->seq1 = p->data;
+        p->seq2 = p->data + max_seq;
+        p->cigar = (uint32_t *)(p->data + 2 * (size_t)max_seq);
+        p->cigar_max_len = max_seq;
+        const bool asm_k = mixed ? ((k & 1u) != 0) : (is_assemble != 0);
+        p->para = asm_k ? sw_parameters{200, -150, -260, -11} : sw_parameters{10, -15, -30, -5};  // sw_avx.c:13-14
+        if (k == 0 && !sw_hip_install(p)) rc = -1;
+        if (ref_len[k] < max_seq) memcpy(p->seq1, ref_bytes + ref_off[k], ref_len[k]);
+        if (seq_len[k] < max_seq) memcpy(p->seq2, seq_bytes + seq_off[k], seq_len[k]);
+        p->len1 = (int16_t)ref_len[k];
+        p->len2 = (int16_t)seq_len[k];
+    }
+    if (rc == 0) rc = sw_hip_align_many(h.data(), n);
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!h[k]) continue;
+        if (rc == 0) {
+            int32_t *r = result + 5 * (size_t)k;
+            r[0] = h[k]->score;
+            r[1] = h[k]->max_i;
+            r[2] = h[k]->max_j;
+            r[3] = h[k]->alignment_offset;
+            r[4] = (int32_t)h[k]->cigar_count;
+            for (uint32_t c = 0; c < h[k]->cigar_count; ++c) cigars[cigar_at[k] + c] = h[k]->cigar[c];
+        }
+        free(h[k]);
+    }
+    return rc;
 }
 
 // Test shim for the two-halves form: alignments k in [batch_start[g], batch_start[g+1]) form request g; `depth` requests are in

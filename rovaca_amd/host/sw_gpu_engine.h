@@ -30,6 +30,12 @@ extern "C" {
 // Unrecoverable device failures log to stderr and exit(EXIT_FAILURE), the reference's convention.
 void sw_hip_run(p_lib_sw_avx p);
 
+// Every handle as sw_hip_run would leave it, in one device call per parameter set -- the C entry for a caller with several
+// alignments at hand, e.g. the assembler, which aligns every haplotype path of a region to the padded reference
+// (apply/assemble/hc_assemble_cigar_cacl.c:417-428; INTEGRATION.md has the patch).  Each handle carries its own sequences,
+// parameters and CIGAR buffer (handles from sw_avx_init).  Returns 0; on a device failure logs to stderr and returns 1.
+int sw_hip_align_many(p_lib_sw_avx *handles, size_t n);
+
 // Points p->avx_function at sw_hip_run when an MI355X is visible and returns 1; returns 0 and leaves the handle alone
 // otherwise (the AVX selection of sw_avx_init stays in force; there is no CPU path in this library).
 int sw_hip_install(p_lib_sw_avx p);

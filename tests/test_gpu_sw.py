@@ -299,3 +299,73 @@ def test_align_batch_in_two_halves_keeps_requests_in_flight(depth):
             o = oracle.sw_align(refs[k], seqs[k], oracle.SW_PARAMS_ASSEMBLE if asm else oracle.SW_PARAMS_GENOTYPE)
             assert tuple(int(x) for x in result[k][:4]) == (o["score"], o["max_i"], o["max_j"], o["alignment_offset"]), k
             assert np.array_equal(cigars[cat[k]:cat[k] + result[k][5]], o["cigar"]), k
+
+
+@pytest.mark.parametrize("mixed", [0, 1])
+def test_c_batch_entry_fills_every_handle_like_the_one_alignment_seam(mixed):
+    # sw_hip_align_many: the C entry for the assembler's call site (hc_assemble_cigar_cacl.c:417-428) -- n handles laid out as
+    # sw_avx_init does, one device call per parameter set, every handle left as sw_hip_run / sw_avx512_run would leave it.
+    # The committed "assemble" goldens (generated from the reference's sw_avx.c) through it, plus the length guard.
+    import ctypes as C
+    L = C.CDLL(os.path.join(os.path.dirname(swapi.__file__), "lib", "librovaca_sw_host.so"))
+    f = L.rovaca_amd_sw_many_through_handles
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    refs, seqs = [], []
+    for t in range(40):
+        n1 = int(rng.integers(30, 700)) if t % 13 else 2048  # a few at the length guard: alignment_offset = 1, nothing else
+        ref = acgt[rng.integers(0, 4, n1)]
+        n2 = int(rng.integers(10, min(n1, 400)))
+        a = int(rng.integers(0, n1 - n2 + 1))
+        seq = ref[a:a + n2].copy()
+        seq[rng.random(n2) < 0.04] = ord("T")
+        if t % 5 == 0:
+            k = int(rng.integers(1, n2 - 1))
+            seq = np.concatenate([seq[:k], acgt[rng.integers(0, 4, 4)], seq[k:]])
+        refs.append(np.ascontiguousarray(ref))
+        seqs.append(np.ascontiguousarray(seq))
+    rb, ro, rl = swapi._tables(refs)
+    sb, so, sl = swapi._tables(seqs)
+    n = len(refs)
+    cigar_at = np.concatenate([[0], np.cumsum(rl + sl + 8)[:-1]]).astype(np.uint32)
+    result = np.zeros((n, 5), np.int32)
+    cigars = np.zeros(int((rl + sl + 8).sum()), np.uint32)
+    ptr = lambda x: x.ctypes.data_as(C.c_void_p)
+    for asm in (0, 1):
+        rc = f(ptr(rb), ptr(ro), ptr(rl), ptr(sb), ptr(so), ptr(sl), n, asm, mixed, ptr(result), ptr(cigars), ptr(cigar_at))
+        assert rc == 0
+        for k in range(n):
+            asm_k = (k & 1) if mixed else asm
+            o = oracle.sw_align(refs[k], seqs[k], oracle.SW_PARAMS_ASSEMBLE if asm_k else oracle.SW_PARAMS_GENOTYPE)
+            if o["too_long"]:
+                assert result[k, 3] == 1 and result[k, 4] == 0
+                continue
+            assert tuple(result[k, :4]) == (o["score"], o["max_i"], o["max_j"], o["alignment_offset"])
+            assert np.array_equal(cigars[cigar_at[k]:cigar_at[k] + result[k, 4]], o["cigar"])
+
+
+@pytest.mark.parametrize("tag", ["genotype", "assemble"])
+def test_c_batch_entry_on_the_reference_made_goldens(tag):
+    # the committed goldens (values the reference's own sw_avx.c returned, oracle/gen_golden_sw.py) through sw_hip_align_many
+    import ctypes as C
+    L = C.CDLL(os.path.join(os.path.dirname(swapi.__file__), "lib", "librovaca_sw_host.so"))
+    f = L.rovaca_amd_sw_many_through_handles
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    g = np.load(GOLD)
+    n = len(g["len1"])
+    rb, ro, rl = np.ascontiguousarray(g["seq1"], np.uint8), np.ascontiguousarray(g["off1"], np.uint32), np.ascontiguousarray(g["len1"], np.uint32)
+    sb, so, sl = np.ascontiguousarray(g["seq2"], np.uint8), np.ascontiguousarray(g["off2"], np.uint32), np.ascontiguousarray(g["len2"], np.uint32)
+    cigar_at = np.concatenate([[0], np.cumsum(rl + sl + 8)[:-1]]).astype(np.uint32)
+    result, cigars = np.zeros((n, 5), np.int32), np.zeros(int((rl + sl + 8).sum()), np.uint32)
+    ptr = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert f(ptr(rb), ptr(ro), ptr(rl), ptr(sb), ptr(so), ptr(sl), n, 1 if tag == "assemble" else 0, 0, ptr(result), ptr(cigars), ptr(cigar_at)) == 0
+    res, gc, coff = g[tag + "_result"], g[tag + "_cigar"], g[tag + "_cigar_off"]
+    for k in range(n):
+        if res[k][4]:
+            assert result[k, 3] == 1 and result[k, 4] == 0
+            continue
+        assert tuple(int(x) for x in result[k, :4]) == tuple(int(x) for x in res[k][:4]), k
+        assert np.array_equal(cigars[cigar_at[k]:cigar_at[k] + result[k, 4]], gc[coff[k]:coff[k + 1]]), k
