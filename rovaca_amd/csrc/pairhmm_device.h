@@ -8,7 +8,10 @@ namespace phmm
 {
 
 constexpr int kLanesPerPair = 16;     // one DPP row per (read, haplotype) pair; four pairs per wave64
-constexpr int kBlockThreads = 256;    // 4 waves = 16 pairs per workgroup
+#ifndef PHMM_BLOCK_THREADS
+#define PHMM_BLOCK_THREADS 256  // tuning aid (tools/build_variant.sh): 128 and 64 measured within 0.5 % on config 2, 1 % worse on config 3
+#endif
+constexpr int kBlockThreads = PHMM_BLOCK_THREADS;    // 4 waves = 16 pairs per workgroup
 constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take the single-pass kernel
 constexpr int kMaxRowsPerLaneWide = 8;  // the one-pair-per-wave shape goes further: 64 * 8 = 512 rows in one pass
 constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other

@@ -511,6 +511,24 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
             step(bM, bX, bY, aM, aX, aY);
     };
 
+#ifndef PHMM_EXPERIMENT_REPEAT
+#define PHMM_EXPERIMENT_REPEAT 1  // tuning experiment (tools/build_variant.sh): sweep every loaded pair this many times -- what a
+#endif                            // read-stationary chain of haplotypes would save on per-pair set-up, measured without building it
+#pragma unroll 1
+    for (int rep = 0; rep < PHMM_EXPERIMENT_REPEAT; ++rep) {
+    if (PHMM_EXPERIMENT_REPEAT > 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool padrow = static_cast<int>(lane) * K + k < pad;
+            M[k] = 0;
+            X[k] = 0;
+            Y[k] = padrow ? init_y : static_cast<T>(0);
+        }
+#pragma unroll
+        for (int k = 0; k + 1 < K; ++k) PM[k] = 0;
+        aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
+        sumM = 0, sumX = 0;
+    }
     uint32_t t = 1;
     // fill: lane l starts at step l + 1
     const uint32_t Tfill = Tmax < (uint32_t)(G - 1) ? Tmax : (uint32_t)(G - 1);
@@ -537,6 +555,7 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHM
     for (; t <= Tmax; ++t) {
         if ((t & 31u) == 1u) reload(t);
         if (t <= Tg) step_t(t);
+    }
     }
     if (valid && lane == G - 1) {
         const T res = sumM + sumX;

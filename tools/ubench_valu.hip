@@ -54,6 +54,10 @@ __global__ void k(float* out, int iters, unsigned long long* clk)
         if (MODE == 28) { REP8(asm volatile("v_pk_add_u16 %0, %0, %2\n v_pk_add_u16 %1, %1, %2\n v_pk_sub_i16 %3, %3, %2\n v_pk_sub_i16 %4, %4, %2\n v_pk_add_u16 %0, %0, %2\n v_pk_add_u16 %1, %1, %2\n v_pk_sub_i16 %3, %3, %2\n v_pk_sub_i16 %4, %4, %2" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 29) { REP8(asm volatile("v_pk_max_i16 %0, %0, %2\n v_pk_max_i16 %1, %1, %2\n v_pk_min_i16 %3, %3, %2\n v_pk_min_u16 %4, %4, %2\n v_pk_max_i16 %0, %0, %2\n v_pk_max_i16 %1, %1, %2\n v_pk_min_i16 %3, %3, %2\n v_pk_min_u16 %4, %4, %2" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 30) { REP8(asm volatile("v_pk_lshrrev_b16 %0, 15, %0\n v_pk_lshlrev_b16 %1, 1, %1\n v_pk_ashrrev_i16 %3, 15, %3\n v_pk_mad_u16 %4, %4, %2, %1\n v_pk_lshrrev_b16 %0, 15, %0\n v_pk_lshlrev_b16 %1, 1, %1\n v_pk_ashrrev_i16 %3, 15, %3\n v_pk_mad_u16 %4, %4, %2, %1" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        if (MODE == 31) { REP8(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));) }
+        if (MODE == 32) { REP8(asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));) }
+        if (MODE == 33) { REP8(asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));) }
+        if (MODE == 34) { REP8(asm volatile("v_cndmask_b32 %0, %2, %3, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %0, %3, %2, vcc\n v_cndmask_b32 %1, %3, %2, vcc\n v_cndmask_b32 %0, %2, %3, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %0, %3, %2, vcc\n v_cndmask_b32 %1, %3, %2, vcc" : "+v"(a0), "+v"(a1) : "v"(b), "v"(c) : );) }
         if (MODE == 7) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -136,6 +140,9 @@ int main()
     run<6>("v_mul/fmac_f32_dpp row_shr:1", out, clk);
     run<4>("v_add_co_u32 + v_cndmask_b32", out, clk);
     run<5>("v_fma_f64 (4 indep)", out, clk);
+    run<31>("v_mul_f64 (4 indep)", out, clk);
+    run<32>("v_add_f64 (4 indep)", out, clk);
+    run<33>("v_fma_f64 (1 dependent chain)", out, clk);
     run<8>("v_add_u32 (4 indep)", out, clk);
     run<9>("v_max_i32 (2 chains)", out, clk);
     run<10>("v_sub_u32 + v_alignbit_b32", out, clk);
