@@ -160,3 +160,61 @@ def test_device_side_preparation_against_the_hand_derived_answers():
         rb.release()
         assert q.tolist() == c["expect"], c["why"]
     eng.close()
+
+
+def _oracle_region(r, min_q=18, model=3):
+    n_reads, n_haps = len(r[3]), len(r[7])
+    w = np.full(n_haps * n_reads, np.nan)
+    ws = np.zeros(n_reads, np.uint32)
+    k = oracle.lib().phmm_oracle_call_region(r[0], r[1], r[2], r[3], r[4], n_reads, r[5], r[6], r[7], n_haps, min_q, model, w, ws)
+    return w.reshape(n_haps, n_reads), ws[:k].copy()
+
+
+def test_region_larger_than_a_stage_takes_the_direct_path():
+    # the batcher's stages hold 64 Ki pairs / 4 096 reads / 1 MiB of sequence; a deeper region is evaluated on the worker's own
+    # context (no batching) -- the same numbers, and it must not disturb the regions that ARE batched around it
+    big = _raw_region(201, reads=4500, haps=3, read_len=(40, 120), hap_len=200, bad_reads=7)      # more reads than a stage holds
+    wide = _raw_region(202, reads=700, haps=100, read_len=(30, 60), hap_len=90)                    # 70 000 pairs
+    small = _raw_region(203, reads=20, haps=5, read_len=(50, 150), hap_len=260)
+    r0, _ = hostapi.batching_stats()
+    for r in (small, big, small, wide, small):
+        got, surv = hostapi.call_region(*r)
+        want, wsurv = _oracle_region(r)
+        assert np.array_equal(surv, wsurv) and np.array_equal(got[:, :len(surv)], want[:, :len(surv)], equal_nan=True)
+    r1, _ = hostapi.batching_stats()
+    assert r1 - r0 == 3  # only the three small ones went through a stage
+
+
+def test_regions_with_different_parameters_never_share_a_submission():
+    # min_quality_threshold and the PCR model are per call: regions that differ in them are kept in separate stages
+    import threading
+    regions = [_raw_region(210 + i, reads=16, haps=4, read_len=(60, 150), hap_len=240, bad_reads=1) for i in range(12)]
+    params = [(18, "CONSERVATIVE"), (10, "NONE"), (18, "HOSTILE"), (25, "AGGRESSIVE")]
+    want = [_oracle_region(r, params[i % 4][0], hostapi.PCR[params[i % 4][1]]) for i, r in enumerate(regions)]
+    errors = []
+
+    def work(i):
+        for _ in range(6):
+            got, surv = hostapi.call_region(*regions[i], min_quality_threshold=params[i % 4][0], pcr_model=params[i % 4][1])
+            if not (np.array_equal(surv, want[i][1]) and np.array_equal(got[:, :len(surv)], want[i][0][:, :len(surv)], equal_nan=True)):
+                errors.append(i)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(regions))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors
+
+
+def test_long_reads_through_the_batcher():
+    # reads of several thousand bases: striped kernels, fp64 re-run, and -- beyond 4 096 bases -- the PCR model's repeat search
+    # working from global memory instead of the set-up launch's LDS copy
+    r = _raw_region(220, reads=6, haps=3, read_len=(3000, 5200), hap_len=5600)
+    got, surv = hostapi.call_region(*r)
+    want, wsurv = _oracle_region(r)
+    assert np.array_equal(surv, wsurv)
+    k = len(surv)  # (reads this long with 1 % errors fall under the filter's -8: usually none survives; the filter must agree)
+    fin = np.isfinite(want[:, :k])
+    assert np.array_equal(np.isfinite(got[:, :k]), fin)
+    if fin.any():
+        assert np.abs(got[:, :k][fin] - want[:, :k][fin]).max() < 1e-9
+    assert np.all(np.isnan(got[:, k:]))

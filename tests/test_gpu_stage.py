@@ -139,3 +139,16 @@ def test_stage_read_preparation_on_tricky_reads(engine, model):
     got_raw, got_l10, _ = engine.compute_regions(raw, reg, prep=(mapq, 18, model))
     want_raw, want_l10, _ = oracle.batch(oracle.prepare_batch(raw, mapq, 18, model), n_threads=4)[:3]
     assert np.array_equal(got_raw.view(np.uint32), want_raw.view(np.uint32))
+
+
+def test_stage_with_reads_beyond_the_set_up_launch_lds_copy(engine):
+    # reads above 4 096 bases: the PCR model's repeat search reads global memory instead of the LDS copy; striped kernels; fp64 re-run
+    b, mapq = _raw(9, n_regions=2, reads=3, haps=2, read_len=(4200, 5000), hap_len=(5200, 5600))
+    rng = np.random.default_rng(9)
+    o, n = int(b.read_off[1]), int(b.read_len[1])
+    b.read_bases[o + 100:o + 400] = np.frombuffer(b"ACG", np.uint8)[np.arange(300) % 3]  # a long tandem repeat inside one read
+    raw, l10, st = engine.compute_regions(b, capi.regions_of(b), prep=(mapq, 18, 3))
+    oraw, ol10, oresc = oracle.batch(oracle.prepare_batch(b, mapq, 18, 3), n_threads=8)
+    assert np.array_equal(raw.view(np.uint32), oraw.view(np.uint32)) and int(st.n_rescued) == int(oresc.sum())
+    fin = np.isfinite(ol10)
+    assert np.array_equal(np.isfinite(l10), fin) and np.abs(l10[fin] - ol10[fin]).max() < 1e-9
