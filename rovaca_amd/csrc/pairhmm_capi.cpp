@@ -39,6 +39,7 @@ int fail(int code, const char *fmt, ...)
 }
 }  // namespace phmm_detail
 using phmm_detail::g_err;
+thread_local PhaseClock *g_phase = nullptr;  // PHMM_PHASE_TIMING: the clock of the call in progress on this thread
 
 // The entry points are implemented in this namespace with C++ linkage; the extern "C" wrappers at the end of the file
 // catch whatever a body may throw (std::bad_alloc from a vector, std::system_error from a thread), so that nothing
@@ -180,35 +181,8 @@ void phmm_release(phmm_context *c, phmm_resident *rb)
     delete rb;
 }
 
-// PHMM_PHASE_TIMING=1: host phases of phmm_compute on stderr (tuning aid)
-struct PhaseClock
-{
-    bool on = getenv("PHMM_PHASE_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    double us[8] = {0};
-    void lap(int i)
-    {
-        if (!on) return;
-        const auto n = std::chrono::steady_clock::now();
-        us[i] += std::chrono::duration<double, std::micro>(n - t).count();
-        t = n;
-    }
-};
-static thread_local PhaseClock *g_phase = nullptr;
-#define PHASE(i) do { if (g_phase) g_phase->lap(i); } while (0)
-
-// How a batch reaches the device.  The defaults are the plain upload; the chunked one-shot call (phmm_compute on a big batch)
-// uploads on a side stream without waiting for the context's stream, and hands in windows of the tables with the pair
-// indices still counted from the start of the caller's tables.
-struct UploadOpts
-{
-    hipStream_t stream = nullptr;  // the copy; null: the context's stream
-    hipStream_t setup_stream = nullptr;  // the fill and the set-up launch; null: the stream of the copy
-    bool caller_synchronised = false;  // the caller knows that nothing on the device still reads this resident's buffers
-    uint32_t read_bias = 0, hap_bias = 0;  // subtracted from pair_read / pair_hap
-};
-
-static int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt = UploadOpts())
+// (PhaseClock / PHASE, UploadOpts: pairhmm_engine.h)
+int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt)
 {
     if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
         return fail(PHMM_E_INVALID, "phmm_upload: pair_read and pair_hap must both be given or both be NULL");
@@ -580,7 +554,7 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
     *out = nullptr;
     phmm_resident *rb = new (std::nothrow) phmm_resident();
     if (!rb) return fail(PHMM_E_NOMEM, "phmm_upload: out of host memory");
-    const int rc = c->cpu ? cpu_upload(c, b, rb) : upload_into(c, b, rb);
+    const int rc = c->cpu ? cpu_upload(c, b, rb) : upload_into(c, b, rb, UploadOpts());
     if (rc != PHMM_OK) {
         delete rb;
         return rc;
@@ -937,389 +911,6 @@ int phmm_download_read_table(phmm_context *c, phmm_resident *rb, uint8_t *qual, 
     return PHMM_OK;
 }
 
-// ---- the chunked one-shot call ----
-// A window of the caller's tables that holds everything a contiguous range of the pair list refers to.
-struct ChunkWindow
-{
-    uint64_t p0 = 0, p1 = 0;               // pairs
-    uint32_t r0 = 0, r1 = 0, h0 = 0, h1 = 0;  // reads [r0, r1), haplotypes [h0, h1)
-    uint64_t rb0 = 0, rb1 = 0, hb0 = 0, hb1 = 0;  // byte ranges of the two tables
-};
-
-constexpr uint64_t kChunkedMinPairs = 1u << 19;  // below this one upload + one sweep is as fast
-constexpr uint64_t kChunkTargetPairs = 1u << 17;
-constexpr unsigned kMaxChunks = 8;
-
-// Cuts the pair list into contiguous chunks and finds each chunk's table windows.  Returns false when chunking would not
-// pay: a small batch, or a pair list that jumps around the tables so that the windows overlap heavily (each chunk would
-// upload most of the tables again).
-static bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
-{
-    const bool cross = b->pair_read == nullptr;
-    const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
-    if (n < kChunkedMinPairs || b->n_reads == 0 || b->n_haps == 0) return false;
-    if (const char *e = phmm_hook("PHMM_NO_CHUNKED_COMPUTE")) {  // tests
-        if (e[0] != '0') return false;
-    }
-    // Chunk sizes rise and fall: the first chunk's packing and the last chunk's conversion are the only host work the device
-    // cannot hide, so those two are small -- 2 % and 8 % of the batch from seven chunks on.
-    unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(2, n / kChunkTargetPairs + 2));
-    std::vector<unsigned> weight(C);
-    for (unsigned k = 0; k < C; ++k) weight[k] = std::min(k + 1, std::min(C - k, 3u));
-    if (C >= 7) {
-        // percent of the batch.  Packing is ~2.6x faster than sweeping, so a chunk may be up to 2.6x the one before it without the
-        // device running dry; the first is as small as a launch can usefully be, the last small enough for a short conversion tail
-        static const unsigned graded[] = {2, 6, 14, 26, 26, 18, 8};
-        C = 7;
-        weight.assign(graded, graded + 7);
-    }
-    if (const char *e = phmm_hook("PHMM_CHUNK_WEIGHTS")) {  // tuning aid: relative chunk sizes, e.g. "1,2,3,2,1"
-        std::vector<unsigned> w;
-        for (const char *q = e; *q;) {
-            char *end = nullptr;
-            const unsigned long v = strtoul(q, &end, 10);
-            if (end == q) break;
-            if (v) w.push_back((unsigned)std::min<unsigned long>(v, 1000));
-            q = *end ? end + 1 : end;
-        }
-        if (w.size() >= 2 && w.size() <= 16) {
-            weight = w;
-            C = (unsigned)w.size();
-        }
-    }
-    std::vector<uint64_t> cut(C + 1, 0);
-    {
-        uint64_t wsum = 0, run = 0;
-        for (unsigned k = 0; k < C; ++k) wsum += weight[k];
-        for (unsigned k = 0; k < C; ++k) {
-            run += weight[k];
-            cut[k + 1] = cross ? (uint64_t)b->n_reads * run / wsum : n * run / wsum;
-        }
-    }
-    plan.assign(C, ChunkWindow());
-    std::atomic<bool> bad{false};
-    parallel_ranges(C, std::min(C, host_threads()), [&](uint64_t lo, uint64_t hi, unsigned) {
-        for (uint64_t k = lo; k < hi; ++k) {
-            ChunkWindow &w = plan[k];
-            if (cross) {
-                w.r0 = (uint32_t)cut[k];
-                w.r1 = (uint32_t)cut[k + 1];
-                w.p0 = (uint64_t)w.r0 * b->n_haps;
-                w.p1 = (uint64_t)w.r1 * b->n_haps;
-                w.h0 = 0;
-                w.h1 = b->n_haps;
-            }
-            else {
-                w.p0 = cut[k];
-                w.p1 = cut[k + 1];
-                uint32_t rmin = UINT32_MAX, rmax = 0, hmin = UINT32_MAX, hmax = 0;
-                for (uint64_t p = w.p0; p < w.p1; ++p) {
-                    const uint32_t r = b->pair_read[p], h = b->pair_hap[p];
-                    rmin = std::min(rmin, r);
-                    rmax = std::max(rmax, r);
-                    hmin = std::min(hmin, h);
-                    hmax = std::max(hmax, h);
-                }
-                if (w.p1 == w.p0 || rmax >= b->n_reads || hmax >= b->n_haps) {
-                    bad.store(true);  // empty chunk or an index out of range: let the plain path report it
-                    return;
-                }
-                w.r0 = rmin;
-                w.r1 = rmax + 1;
-                w.h0 = hmin;
-                w.h1 = hmax + 1;
-            }
-            uint64_t lo_b = UINT64_MAX, hi_b = 0;
-            for (uint32_t r = w.r0; r < w.r1; ++r) {
-                lo_b = std::min<uint64_t>(lo_b, b->read_off[r]);
-                hi_b = std::max<uint64_t>(hi_b, (uint64_t)b->read_off[r] + b->read_len[r]);
-            }
-            w.rb0 = w.r1 > w.r0 ? lo_b : 0;
-            w.rb1 = w.r1 > w.r0 ? hi_b : 0;
-            lo_b = UINT64_MAX;
-            hi_b = 0;
-            for (uint32_t h = w.h0; h < w.h1; ++h) {
-                lo_b = std::min<uint64_t>(lo_b, b->hap_off[h]);
-                hi_b = std::max<uint64_t>(hi_b, (uint64_t)b->hap_off[h] + b->hap_len[h]);
-            }
-            w.hb0 = w.h1 > w.h0 ? lo_b : 0;
-            w.hb1 = w.h1 > w.h0 ? hi_b : 0;
-        }
-    });
-    if (bad.load()) return false;
-    uint64_t win_bytes = 0, all_lo = UINT64_MAX, all_hi = 0, hall_lo = UINT64_MAX, hall_hi = 0;
-    for (const ChunkWindow &w : plan) {
-        if (w.p1 == w.p0) return false;
-        win_bytes += 5 * (w.rb1 - w.rb0) + (w.hb1 - w.hb0);
-        all_lo = std::min(all_lo, w.rb0);
-        all_hi = std::max(all_hi, w.rb1);
-        hall_lo = std::min(hall_lo, w.hb0);
-        hall_hi = std::max(hall_hi, w.hb1);
-    }
-    const uint64_t once = 5 * (all_hi - all_lo) + (hall_hi - hall_lo);
-    return win_bytes <= once + once / 2 + (1u << 20);
-}
-
-// The chunked one-shot call as a two-thread pipeline.  The calling thread bins, packs and enqueues chunk after chunk without ever
-// waiting for the device (upload + set-up on the upload stream, the sweep behind an event on the context's stream, the result
-// copy behind another event on the download stream, so that the next sweep starts the moment this one ends); a collector thread
-// takes the chunks in order as their results arrive, fetches the fp64 sums where anything was rescued, and does the host log10.
-// Three resident slots: chunk k is packed while k - 1 is swept and k - 2 is being converted.  The device queue stays non-empty
-// from the first chunk's sweep to the last one's -- round 2 packed chunk k + 1 only after chunk k - 1 had been collected, and the
-// sweeps of one call took 10.0 ms for 8.3 ms of work because the clock ramped down in the gaps.
-static int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<ChunkWindow> &plan, float *out_raw_f32,
-                           double *out_log10, phmm_stats *stats)
-{
-    HIP_TRY(hipSetDevice(c->device));
-    constexpr int S = phmm_context::kChunkSlots;
-    for (int i = 0; i < S; ++i) {
-        if (!c->chunk_slot[i]) {
-            c->chunk_slot[i] = new (std::nothrow) phmm_resident();
-            if (!c->chunk_slot[i]) return fail(PHMM_E_NOMEM, "phmm_compute: out of host memory");
-        }
-        if (!c->chunk_up[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_up[i], hipEventDisableTiming));
-        if (!c->chunk_swept[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_swept[i], hipEventDisableTiming));
-        if (!c->chunk_done[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming));
-    }
-    if (!c->down) HIP_TRY(hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking));
-    hipStream_t up = c->side[phmm_context::kSideStreams - 1];  // not used by the sweeps (n_side defaults to 2 of 3)
-    if (c->n_side >= phmm_context::kSideStreams) up = c->stream;
-    hipStream_t down = c->down;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // nothing of an earlier call still reads the slots
-    if (up != c->stream) HIP_TRY(hipStreamSynchronize(up));
-    HIP_TRY(hipStreamSynchronize(down));
-    const bool cross = b->pair_read == nullptr;
-    const size_t n_chunks = plan.size();
-    const bool trace = getenv("PHMM_PHASE_TIMING") != nullptr;  // tuning aid: host time line of the pipeline on stderr
-    const bool direct = phmm_hook("PHMM_CHUNK_RESULTS_BY_COPY") == nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
-
-    struct InFlight
-    {
-        const ChunkWindow *w = nullptr;
-        size_t count_at = 0;
-    } fl[S];
-    // hand-off between the two threads: chunks [0, enqueued) are on the device, [0, collected) are finished
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t enqueued = 0, collected = 0;
-    bool producer_failed = false;
-    int collector_rc = PHMM_OK;
-    std::string collector_msg;
-    phmm_stats total{};
-
-    auto collect = [&](size_t k) -> int {
-        const int slot = (int)(k % S);
-        phmm_resident *rb = c->chunk_slot[slot];
-        const ChunkWindow &w = *fl[slot].w;
-        const uint64_t n = rb->n_pairs;
-        HIP_TRY(hipEventSynchronize(c->chunk_done[slot]));
-        const double t_ready = trace ? now_us() : 0.0;
-        const size_t off_cnt = fl[slot].count_at * sizeof(float), off64 = off_cnt + 256;
-        const uint8_t *st = static_cast<const uint8_t *>(rb->out_stage.p);
-        const float *rp = reinterpret_cast<const float *>(st);
-        const double *r64 = reinterpret_cast<const double *>(st + off64);
-        bool want64 = true;  // results written by the kernels straight into the pinned stage: the fp64 sums are there already
-        if (!direct) {
-            const uint32_t *counts = reinterpret_cast<const uint32_t *>(st + off_cnt);
-            rb->last_rescued = 0;
-            for (int qi = 0; qi < kQueues; ++qi) rb->last_rescued += counts[qi];
-            want64 = out_log10 && rb->last_rescued;
-            if (want64) {
-                // the rescue kernels of this chunk are done (the event above follows them); the copy runs beside the next sweep
-                HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(st) + off64, rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, down));
-                HIP_TRY(hipStreamSynchronize(down));
-            }
-        }
-        if (out_raw_f32) memcpy(out_raw_f32 + w.p0, rp, n * sizeof(float));
-        std::atomic<uint64_t> n_resc{0};
-        {
-            double *dst = out_log10 ? out_log10 + w.p0 : nullptr;
-            auto finalize = [&](uint64_t lo, uint64_t hi, unsigned) {  // pairhmm_internal.cpp:577-585
-                uint64_t resc = 0;
-                for (uint64_t p = lo; p < hi; ++p) {
-                    const float x = rp[p];
-                    if (x < PHMM_MIN_ACCEPTED_F32) {
-                        ++resc;
-                        if (dst) dst[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
-                    }
-                    else if (dst) {
-                        dst[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
-                    }
-                }
-                n_resc.fetch_add(resc, std::memory_order_relaxed);
-            };
-            if (n >= (1u << 14))
-                parallel_ranges(n, c->fin_pool->helpers() + 1u, finalize);
-            else
-                finalize(0, n, 0);
-        }
-        rb->last_rescued = (uint32_t)n_resc.load();
-        total.cells += rb->cells;
-        total.n_rescued += rb->last_rescued;
-        total.n_launches += (uint32_t)rb->bins.size();
-        if (!rb->bins.empty()) total.max_rows_per_lane = std::max<uint32_t>(total.max_rows_per_lane, (uint32_t)rb->bins.back().rows_per_lane);
-        if (trace) fprintf(stderr, "phmm chunk %zu: results on the host at %.0f us, converted at %.0f us\n", k, t_ready, now_us());
-        return PHMM_OK;
-    };
-
-    std::thread collector([&] {
-        (void)hipSetDevice(c->device);
-        phmm_detail::PoolScope pool(c->fin_pool);
-        for (size_t k = 0; k < n_chunks; ++k) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return enqueued > k || producer_failed; });
-                if (enqueued <= k) return;  // the producer gave up before this chunk
-            }
-            int rc = PHMM_OK;
-            try {
-                rc = collect(k);
-            }
-            catch (...) {
-                rc = fail(PHMM_E_NOMEM, "phmm_compute: the collector thread ran out of memory");
-            }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (rc != PHMM_OK && collector_rc == PHMM_OK) {
-                    collector_rc = rc;
-                    collector_msg = g_err;  // (thread-local: carry the text over)
-                }
-                collected = k + 1;
-            }
-            cv.notify_all();
-        }
-    });
-    struct Joiner  // whichever way this function returns, the collector is told and joined first
-    {
-        std::thread &t;
-        std::mutex &mu;
-        std::condition_variable &cv;
-        bool &failed;
-        bool ok = false;
-        ~Joiner()
-        {
-            if (!ok) {
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    failed = true;
-                }
-                cv.notify_all();
-            }
-            t.join();
-        }
-    } joiner{collector, mu, cv, producer_failed};
-
-    phmm_detail::PoolScope pool(c->pack_pool);
-    std::vector<uint32_t> roff, hoff;
-    for (size_t k = 0; k < n_chunks; ++k) {
-        const ChunkWindow &w = plan[k];
-        const int slot = (int)(k % S);
-        if (k >= (size_t)S) {  // the slot held chunk k - S: its results must have left it
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return collected + S > k; });
-            if (collector_rc != PHMM_OK) break;
-        }
-        const double t_a = trace ? now_us() : 0.0;
-        phmm_resident *rb = c->chunk_slot[slot];
-        // the chunk as a batch of its own: windows of the tables, offsets rebased to the windows, pair indices biased
-        phmm_batch s = *b;
-        s.n_reads = w.r1 - w.r0;
-        s.n_haps = w.h1 - w.h0;
-        s.n_pairs = w.p1 - w.p0;
-        roff.resize(s.n_reads);
-        for (uint32_t r = 0; r < s.n_reads; ++r) roff[r] = (uint32_t)(b->read_off[w.r0 + r] - w.rb0);
-        hoff.resize(s.n_haps);
-        for (uint32_t h = 0; h < s.n_haps; ++h) hoff[h] = (uint32_t)(b->hap_off[w.h0 + h] - w.hb0);
-        s.read_bases = b->read_bases + w.rb0;
-        s.read_qual = b->read_qual + w.rb0;
-        s.read_ins = b->read_ins ? b->read_ins + w.rb0 : nullptr;
-        s.read_del = b->read_del ? b->read_del + w.rb0 : nullptr;
-        s.read_gcp = b->read_gcp ? b->read_gcp + w.rb0 : nullptr;
-        s.read_off = roff.data();
-        s.read_len = b->read_len + w.r0;
-        s.hap_bases = b->hap_bases + w.hb0;
-        s.hap_off = hoff.data();
-        s.hap_len = b->hap_len + w.h0;
-        s.pair_read = cross ? nullptr : b->pair_read + w.p0;
-        s.pair_hap = cross ? nullptr : b->pair_hap + w.p0;
-        phmm_read_prep prep_k;
-        if (b->prep) {
-            prep_k = *b->prep;
-            prep_k.read_mapq = b->prep->read_mapq ? b->prep->read_mapq + w.r0 : nullptr;
-            s.prep = &prep_k;
-        }
-        UploadOpts opt;
-        opt.stream = up;
-        opt.caller_synchronised = true;  // slot `slot` held chunk k - S: collected (see above), so its sweep is long over
-        opt.read_bias = cross ? 0 : w.r0;
-        opt.hap_bias = cross ? 0 : w.h0;
-        // The copy travels on the upload stream (DMA engines: it runs beside the previous chunk's sweep); the set-up launch goes on
-        // the context's stream, in front of this chunk's sweep.  On the upload stream it would not start before the previous sweep
-        // has handed out its last workgroup -- small kernels of another queue are starved by a grid that fills the chip -- and the
-        // sweep behind it would wait with it: 90-110 us of a drained chip at every chunk boundary (rocprofv3 time line, round 3).
-        opt.setup_stream = c->stream;
-        if (k == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-        PhaseClock chunk_clock;
-        struct PhaseScope
-        {
-            explicit PhaseScope(PhaseClock *p) { g_phase = p; }
-            ~PhaseScope() { g_phase = nullptr; }
-        } phase_scope(trace ? &chunk_clock : nullptr);
-        int rc = upload_into(c, &s, rb, opt);
-        if (rc != PHMM_OK) return rc;
-        // where the sums go: straight into the slot's pinned result block (the kernels write host memory over PCIe: no copy, no
-        // cross-stream event between two sweeps), or -- PHMM_CHUNK_RESULTS_BY_COPY=1 -- into HBM and from there by a copy
-        const uint64_t n = rb->n_pairs;
-        const size_t count_at = (n + 63) & ~size_t(63);
-        HIP_TRY(rb->out_stage.ensure(count_at * sizeof(float) + 256 + n * sizeof(double)));
-        rb->out32_host = direct ? static_cast<float *>(rb->out_stage.p) : nullptr;
-        rb->out64_host = direct ? reinterpret_cast<double *>(static_cast<uint8_t *>(rb->out_stage.p) + count_at * sizeof(float) + 256) : nullptr;
-        rc = impl::phmm_sweep(c, rb);
-        if (rc != PHMM_OK) return rc;
-        PHASE(4);
-        if (k + 1 == n_chunks) HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        if (direct) {
-            HIP_TRY(hipEventRecord(c->chunk_done[slot], c->stream));
-        }
-        else {
-            // the sums travel on the download stream: the next chunk's sweep does not queue behind the copy
-            HIP_TRY(hipEventRecord(c->chunk_swept[slot], c->stream));
-            HIP_TRY(hipStreamWaitEvent(down, c->chunk_swept[slot], 0));
-            HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, count_at * sizeof(float) + kQueues * sizeof(uint32_t), hipMemcpyDeviceToHost, down));
-            HIP_TRY(hipEventRecord(c->chunk_done[slot], down));
-        }
-        fl[slot].w = &w;
-        fl[slot].count_at = count_at;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            enqueued = k + 1;
-        }
-        cv.notify_all();
-        if (trace) {
-            PHASE(5);
-            fprintf(stderr, "phmm chunk %zu: %llu pairs, packed and enqueued %.0f..%.0f us (validate %.0f pack %.0f bin %.0f copy+setup %.0f sweep-enqueue %.0f results-enqueue %.0f)\n",
-                    k, (unsigned long long)(w.p1 - w.p0), t_a, now_us(), chunk_clock.us[0], chunk_clock.us[1], chunk_clock.us[2], chunk_clock.us[3],
-                    chunk_clock.us[4], chunk_clock.us[5]);
-        }
-    }
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return collected >= enqueued || collector_rc != PHMM_OK; });
-    }
-    joiner.ok = enqueued == n_chunks;
-    if (collector_rc != PHMM_OK) return fail(collector_rc, "%s", collector_msg.c_str());
-    if (enqueued != n_chunks) return fail(PHMM_E_INVALID, "phmm_compute: the chunk pipeline stopped early");
-    if (stats) {
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        total.kernel_ms = ms;
-        *stats = total;
-    }
-    return PHMM_OK;
-}
-
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats)
 {
     if (!c || !b) return fail(PHMM_E_INVALID, "phmm_compute: null argument");
@@ -1345,8 +936,8 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
         phmm_detail::PoolScope pool(n_all >= kChunkedMinPairs ? c->pack_pool : nullptr);
         const bool tables_ok = b->read_bases && b->read_qual && b->read_off && b->read_len && b->hap_bases && b->hap_off && b->hap_len &&
                                ((b->pair_read == nullptr) == (b->pair_hap == nullptr)) && (b->prep ? b->prep->read_mapq != nullptr : true);
-        if (tables_ok && plan_chunks(b, plan)) {
-            const int rc = compute_chunked(c, b, plan, out_raw_f32, out_log10, stats);
+        if (tables_ok && impl::plan_chunks(b, plan)) {
+            const int rc = impl::compute_chunked(c, b, plan, out_raw_f32, out_log10, stats);
             if (rc == PHMM_OK && stats)
                 stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             return rc;
@@ -1363,7 +954,7 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
         explicit PhaseScope(PhaseClock *p) { g_phase = p; }
         ~PhaseScope() { g_phase = nullptr; }
     } phase_scope(clock.on ? &clock : nullptr);
-    int rc = upload_into(c, b, rb);
+    int rc = upload_into(c, b, rb, UploadOpts());
     if (rc != PHMM_OK) return rc;
     // one pass; the events are read only after the download's synchronisation (no extra round trip for the timing)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -1389,435 +980,8 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
 
 }  // namespace impl
 
-// ----------------------------------------------------------------------------------------------------
-// Several devices behind one handle (SURVEY.md 8b "create(device_ids[], n)", 8e): pairs are independent, so a batch is cut
-// into one slice per device -- contiguous ranges of the length-binned order (rows per lane, haplotype length, pair index),
-// equal in DP cells, not in pairs -- and every device works its slice on its own host thread with its own context (stream
-// set, staging, tables).  There is no exchange step and no collective; results land at the pairs' own positions of the
-// caller's arrays, which are disjoint between devices.
-// ----------------------------------------------------------------------------------------------------
-struct phmm_multi
-{
-    std::vector<phmm_context *> ctx;
-};
-
-struct phmm_multi_resident
-{
-    uint64_t n_pairs = 0;
-    std::vector<phmm_resident *> part;            // one per device (never null; a slice may be empty)
-    std::vector<std::vector<uint32_t>> index;     // pair ids of each slice, in slice order
-    std::vector<std::vector<uint32_t>> pr, ph;    // the slices' pair lists (kept: phmm_upload_into copies them, but cheap)
-    std::vector<uint64_t> cells;
-};
-
 namespace impl
 {
-
-// run fn(device index) on one thread per device; the first failure's status and text are handed to the calling thread
-// `degraded` (nullable) is set before any un-started body runs on the caller when a helper thread could not be created: bodies
-// that meet at a gate must then stop waiting for each other (they run one after another)
-template <typename F>
-static int on_every_device(phmm_multi *m, F &&fn, std::atomic<bool> *degraded = nullptr)
-{
-    const size_t n = m->ctx.size();
-    std::vector<int> rc(n, PHMM_OK);
-    std::vector<std::string> msg(n);
-    auto body = [&](size_t g) {
-        try {
-            rc[g] = fn(g);
-        }
-        catch (const std::bad_alloc &) {
-            rc[g] = fail(PHMM_E_NOMEM, "out of host memory on the thread of device %d", m->ctx[g]->device);
-        }
-        catch (...) {
-            rc[g] = fail(PHMM_E_INVALID, "unexpected exception on the thread of device %d", m->ctx[g]->device);
-        }
-        if (rc[g] != PHMM_OK) msg[g] = g_err;  // g_err is thread-local: copy it out of the worker
-    };
-    std::vector<std::thread> th;
-    th.reserve(n);
-    size_t started = 1;
-    try {
-        for (; started < n; ++started) th.emplace_back(body, started);
-    }
-    catch (...) {
-    }
-    if (started < n && degraded) degraded->store(true, std::memory_order_release);
-    body(0);
-    for (size_t g = started; g < n; ++g) body(g);
-    for (auto &t : th) t.join();
-    for (size_t g = 0; g < n; ++g)
-        if (rc[g] != PHMM_OK) return fail(rc[g], "device %d: %s", m->ctx[g]->device, msg[g].c_str());
-    return PHMM_OK;
-}
-
-void phmm_destroy_multi(phmm_multi *m)
-{
-    if (!m) return;
-    for (phmm_context *c : m->ctx) impl::phmm_destroy(c);
-    delete m;
-}
-
-int phmm_create_multi(const int *device_ids, int n_devices, phmm_multi **out)
-{
-    if (!out || !device_ids || n_devices < 1) return fail(PHMM_E_INVALID, "phmm_create_multi: bad arguments");
-    *out = nullptr;
-    // PHMM_MULTI_ALLOW_SHARED_DEVICE=1 (tests, and bench.py --oversubscribe): a device may be listed several times -- every
-    // entry still gets its own context, host thread and slice, so the whole N-slice path runs on a box with fewer than N GPUs
-    const bool shared_ok = getenv("PHMM_MULTI_ALLOW_SHARED_DEVICE") != nullptr;
-    for (int i = 0; i < n_devices && !shared_ok; ++i)
-        for (int j = 0; j < i; ++j)
-            if (device_ids[i] == device_ids[j])
-                return fail(PHMM_E_INVALID, "phmm_create_multi: device %d is listed twice (one context per device)", device_ids[i]);
-    phmm_multi *m = new phmm_multi();
-    for (int i = 0; i < n_devices; ++i) {
-        phmm_context *c = nullptr;
-        const int rc = impl::phmm_create(device_ids[i], nullptr, &c);
-        if (rc != PHMM_OK) {
-            impl::phmm_destroy_multi(m);
-            return rc;
-        }
-        m->ctx.push_back(c);
-    }
-    *out = m;
-    return PHMM_OK;
-}
-
-// the same handle over CPU contexts (phmm_create_cpu): the cut, the per-slice threads, the scatter of the results and the timed
-// gate are the code the device slices run, so the N > 1 path is exercised on a machine without GPUs
-int phmm_create_multi_cpu(int n_slices, int n_threads_each, int allow_simd, phmm_multi **out)
-{
-    if (!out || n_slices < 1 || n_threads_each < 0) return fail(PHMM_E_INVALID, "phmm_create_multi_cpu: bad arguments");
-    *out = nullptr;
-    phmm_multi *m = new phmm_multi();
-    for (int i = 0; i < n_slices; ++i) {
-        phmm_context *c = nullptr;
-        const int rc = impl::phmm_create_cpu(n_threads_each, allow_simd, &c);
-        if (rc != PHMM_OK) {
-            impl::phmm_destroy_multi(m);
-            return rc;
-        }
-        c->device = -1 - i;  // (only a label: phmm_multi_device_id reports -1, -2, ... for CPU slices)
-        m->ctx.push_back(c);
-    }
-    *out = m;
-    return PHMM_OK;
-}
-
-void phmm_multi_release(phmm_multi *m, phmm_multi_resident *rb)
-{
-    if (!rb) return;
-    for (size_t g = 0; g < rb->part.size(); ++g) impl::phmm_release(m && g < m->ctx.size() ? m->ctx[g] : nullptr, rb->part[g]);
-    delete rb;
-}
-
-// the cut: pairs sorted by (rows per lane = ceil(R / 16), haplotype length, index), then n contiguous slices of near-equal
-// cells (each cut within one pair of the ideal)
-static int partition_equal_cells(const phmm_batch *b, size_t n_dev, phmm_multi_resident *rb)
-{
-    if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
-        return fail(PHMM_E_INVALID, "phmm_multi_upload: pair_read and pair_hap must both be given or both be NULL");
-    const bool cross = b->pair_read == nullptr;
-    const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
-    if (n > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_multi_upload: more than 2^32 pairs in one batch");
-    if (n && (!b->read_len || !b->hap_len || !b->read_off || !b->hap_off || !b->read_bases || !b->read_qual || !b->hap_bases))
-        return fail(PHMM_E_INVALID, "phmm_multi_upload: null table pointer");
-    if (n && !b->prep && (!b->read_ins || !b->read_del || !b->read_gcp))
-        return fail(PHMM_E_INVALID, "phmm_multi_upload: null gap-penalty array (and no phmm_read_prep given)");
-    if (b->prep && (!b->prep->read_mapq || b->prep->pcr_model < 0 || b->prep->pcr_model > 3)) return fail(PHMM_E_INVALID, "phmm_multi_upload: bad phmm_read_prep");
-    rb->n_pairs = n;
-    std::vector<uint64_t> keys(n);
-    std::atomic<uint64_t> bad{UINT64_MAX};
-    auto pair_of = [&](uint64_t p, uint32_t &r, uint32_t &h) {
-        if (cross) {
-            r = (uint32_t)(p / b->n_haps);
-            h = (uint32_t)(p % b->n_haps);
-        }
-        else {
-            r = b->pair_read[p];
-            h = b->pair_hap[p];
-        }
-    };
-    const unsigned T = n >= kParallelMinPairs ? host_threads() : 1u;
-    parallel_ranges(n, T, [&](uint64_t lo, uint64_t hi, unsigned) {
-        for (uint64_t p = lo; p < hi; ++p) {
-            uint32_t r, h;
-            pair_of(p, r, h);
-            if (r >= b->n_reads || h >= b->n_haps) {
-                uint64_t expect = UINT64_MAX;
-                bad.compare_exchange_strong(expect, p);
-                return;
-            }
-            const uint64_t k = (b->read_len[r] + phmm::kLanesPerPair - 1) / phmm::kLanesPerPair;
-            keys[p] = (k << 52) | ((uint64_t)(b->hap_len[h] & 0xFFFFFu) << 32) | p;  // lengths were checked < 2^20 by upload
-        }
-    });
-    if (bad.load() != UINT64_MAX)
-        return fail(PHMM_E_INVALID, "phmm_multi_upload: pair %llu indexes outside the tables", (unsigned long long)bad.load());
-    std::sort(keys.begin(), keys.end());
-    std::vector<uint64_t> cum(n);
-    uint64_t run = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        uint32_t r, h;
-        pair_of(keys[i] & 0xFFFFFFFFull, r, h);
-        run += (uint64_t)b->read_len[r] * b->hap_len[h];
-        cum[i] = run;
-    }
-    rb->index.assign(n_dev, {});
-    rb->pr.assign(n_dev, {});
-    rb->ph.assign(n_dev, {});
-    rb->cells.assign(n_dev, 0);
-    uint64_t prev = 0;
-    for (size_t g = 0; g < n_dev; ++g) {
-        uint64_t cut = n;
-        if (g + 1 < n_dev) {
-            const long double target = (long double)run * (long double)(g + 1) / (long double)n_dev;
-            cut = (uint64_t)(std::lower_bound(cum.begin(), cum.end(), target, [](uint64_t c, long double t) { return (long double)c < t; }) - cum.begin());
-            cut = std::max(cut, prev);
-        }
-        rb->index[g].resize(cut - prev);
-        rb->pr[g].resize(cut - prev);
-        rb->ph[g].resize(cut - prev);
-        for (uint64_t i = prev; i < cut; ++i) {
-            const uint32_t p = (uint32_t)(keys[i] & 0xFFFFFFFFull);
-            uint32_t r, h;
-            pair_of(p, r, h);
-            rb->index[g][i - prev] = p;
-            rb->pr[g][i - prev] = r;
-            rb->ph[g][i - prev] = h;
-        }
-        rb->cells[g] = (cut ? cum[cut - 1] : 0) - (prev ? cum[prev - 1] : 0);
-        prev = cut;
-    }
-    return PHMM_OK;
-}
-
-// A slice as a batch of its own: only the reads and haplotypes its pairs refer to, packed into tables of its own (a slice is a
-// run of the length-binned ORDER, so its reads lie all over the caller's tables: windows would not do), indices remapped.  Every
-// device therefore packs, uploads and prepares its own share of the tables instead of the whole batch (round 2 handed every
-// device the full tables: N times the upload and N times the haplotype planes).
-struct SliceTables
-{
-    std::vector<uint8_t> bases, qual, ins, del, gcp, mapq, haps;
-    std::vector<uint32_t> roff, rlen, hoff, hlen, pr, ph;
-    phmm_read_prep prep{};
-    phmm_batch view{};
-};
-static void slice_of(const phmm_batch *b, const phmm_multi_resident *rb, size_t g, SliceTables &t)
-{
-    const std::vector<uint32_t> &gpr = rb->pr[g], &gph = rb->ph[g];
-    const size_t n = gpr.size();
-    constexpr uint32_t kNone = 0xFFFFFFFFu;
-    std::vector<uint32_t> rmap(b->n_reads, kNone), hmap(b->n_haps, kNone);
-    t.pr.resize(n ? n : 1);
-    t.ph.resize(n ? n : 1);
-    const bool has_gap_arrays = b->prep == nullptr;
-    for (size_t i = 0; i < n; ++i) {
-        const uint32_t r = gpr[i], h = gph[i];
-        if (rmap[r] == kNone) {
-            rmap[r] = (uint32_t)t.rlen.size();
-            const uint32_t o = b->read_off[r], len = b->read_len[r];
-            t.roff.push_back((uint32_t)t.bases.size());
-            t.rlen.push_back(len);
-            t.bases.insert(t.bases.end(), b->read_bases + o, b->read_bases + o + len);
-            t.qual.insert(t.qual.end(), b->read_qual + o, b->read_qual + o + len);
-            if (has_gap_arrays) {
-                t.ins.insert(t.ins.end(), b->read_ins + o, b->read_ins + o + len);
-                t.del.insert(t.del.end(), b->read_del + o, b->read_del + o + len);
-                t.gcp.insert(t.gcp.end(), b->read_gcp + o, b->read_gcp + o + len);
-            }
-            else {
-                t.mapq.push_back(b->prep->read_mapq[r]);
-            }
-        }
-        if (hmap[h] == kNone) {
-            hmap[h] = (uint32_t)t.hlen.size();
-            const uint32_t o = b->hap_off[h], len = b->hap_len[h];
-            t.hoff.push_back((uint32_t)t.haps.size());
-            t.hlen.push_back(len);
-            t.haps.insert(t.haps.end(), b->hap_bases + o, b->hap_bases + o + len);
-        }
-        t.pr[i] = rmap[r];
-        t.ph[i] = hmap[h];
-    }
-    phmm_batch &s = t.view;
-    s = phmm_batch{};
-    s.n_reads = (uint32_t)t.rlen.size();
-    s.n_haps = (uint32_t)t.hlen.size();
-    s.n_pairs = n;
-    s.read_bases = t.bases.data();
-    s.read_qual = t.qual.data();
-    s.read_ins = has_gap_arrays ? t.ins.data() : nullptr;
-    s.read_del = has_gap_arrays ? t.del.data() : nullptr;
-    s.read_gcp = has_gap_arrays ? t.gcp.data() : nullptr;
-    s.read_off = t.roff.data();
-    s.read_len = t.rlen.data();
-    s.hap_bases = t.haps.data();
-    s.hap_off = t.hoff.data();
-    s.hap_len = t.hlen.data();
-    s.pair_read = t.pr.data();  // (never null: an empty slice must not read as "full cross product")
-    s.pair_hap = t.ph.data();
-    if (b->prep) {
-        t.prep = *b->prep;
-        t.prep.read_mapq = t.mapq.data();
-        s.prep = &t.prep;
-    }
-}
-
-int phmm_multi_upload(phmm_multi *m, const phmm_batch *b, phmm_multi_resident **out)
-{
-    if (!m || !b || !out) return fail(PHMM_E_INVALID, "phmm_multi_upload: null argument");
-    *out = nullptr;
-    phmm_multi_resident *rb = new phmm_multi_resident();
-    int rc = partition_equal_cells(b, m->ctx.size(), rb);
-    if (rc == PHMM_OK) {
-        rb->part.assign(m->ctx.size(), nullptr);
-        rc = on_every_device(m, [&](size_t g) {
-            SliceTables t;  // (the upload copies what it needs: the slice's tables may go when it returns)
-            slice_of(b, rb, g, t);
-            return impl::phmm_upload(m->ctx[g], &t.view, &rb->part[g]);
-        });
-    }
-    if (rc != PHMM_OK) {
-        impl::phmm_multi_release(m, rb);
-        return rc;
-    }
-    *out = rb;
-    return PHMM_OK;
-}
-
-int phmm_multi_sweep(phmm_multi *m, phmm_multi_resident *rb)
-{
-    if (!m || !rb) return fail(PHMM_E_INVALID, "phmm_multi_sweep: null argument");
-    // enqueue only (asynchronous): cheap enough to do from the calling thread, device after device
-    for (size_t g = 0; g < m->ctx.size(); ++g) {
-        const int rc = impl::phmm_sweep(m->ctx[g], rb->part[g]);
-        if (rc != PHMM_OK) return rc;
-    }
-    return PHMM_OK;
-}
-
-int phmm_multi_synchronize(phmm_multi *m)
-{
-    if (!m) return fail(PHMM_E_INVALID, "phmm_multi_synchronize: null argument");
-    for (phmm_context *c : m->ctx) {
-        const int rc = impl::phmm_synchronize(c);
-        if (rc != PHMM_OK) return rc;
-    }
-    return PHMM_OK;
-}
-
-int phmm_multi_sweep_timed(phmm_multi *m, phmm_multi_resident *rb, int iters, double *wall_ms_per_pass, double *device_ms_per_pass,
-                           double *fp32_ms_per_pass)
-{
-    if (!m || !rb || iters < 1 || !wall_ms_per_pass) return fail(PHMM_E_INVALID, "phmm_multi_sweep_timed: bad arguments");
-    const size_t n = m->ctx.size();
-    // every device thread waits at the gate, sweeps `iters` passes bracketed by HIP events on its own stream and reports its
-    // wall time from the common start; the job's time is the slowest device's
-    // (the gate is used only while every device has a thread of its own: when a helper thread could not be started the
-    // remaining bodies run one after another on the caller, `serial` is set first and nobody waits for a body that has not begun;
-    // the common start is then the call's own)
-    std::atomic<size_t> arrived{0};
-    std::atomic<bool> go{false}, serial{false};
-    const auto t_entry = std::chrono::steady_clock::now();
-    std::atomic<int64_t> start_ns{0};  // offset of the common start from t_entry
-    std::vector<double> wall(n, 0.0), dev(n, 0.0), f32(n, 0.0);
-    const int rc = on_every_device(m, [&](size_t g) {
-        int r = impl::phmm_synchronize(m->ctx[g]);
-        if (arrived.fetch_add(1) + 1 == n && !serial.load(std::memory_order_acquire)) {
-            start_ns.store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count());
-            go.store(true, std::memory_order_release);
-        }
-        while (!go.load(std::memory_order_acquire) && !serial.load(std::memory_order_acquire)) std::this_thread::yield();
-        if (r != PHMM_OK) return r;
-        r = impl::phmm_sweep_timed(m->ctx[g], rb->part[g], iters, &dev[g], &f32[g]);
-        if (r == PHMM_OK) r = impl::phmm_synchronize(m->ctx[g]);
-        const auto t_start = t_entry + std::chrono::nanoseconds(start_ns.load());
-        wall[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-        return r;
-    }, &serial);
-    if (rc != PHMM_OK) return rc;
-    double w = 0.0;
-    for (size_t g = 0; g < n; ++g) w = std::max(w, wall[g]);
-    *wall_ms_per_pass = w / iters;
-    for (size_t g = 0; g < n; ++g) {
-        if (device_ms_per_pass) device_ms_per_pass[g] = dev[g];
-        if (fp32_ms_per_pass) fp32_ms_per_pass[g] = f32[g];
-    }
-    return PHMM_OK;
-}
-
-int phmm_multi_download(phmm_multi *m, phmm_multi_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats)
-{
-    if (!m || !rb) return fail(PHMM_E_INVALID, "phmm_multi_download: null argument");
-    const size_t n = m->ctx.size();
-    std::vector<phmm_stats> st(n);
-    const int rc = on_every_device(m, [&](size_t g) -> int {
-        const size_t k = rb->index[g].size();
-        std::vector<float> raw(out_raw_f32 ? k : 0);
-        std::vector<double> l10(out_log10 ? k : 0);
-        const int r = impl::phmm_download(m->ctx[g], rb->part[g], out_raw_f32 ? raw.data() : nullptr, out_log10 ? l10.data() : nullptr, &st[g]);
-        if (r != PHMM_OK) return r;
-        const uint32_t *idx = rb->index[g].data();
-        if (out_raw_f32)
-            for (size_t i = 0; i < k; ++i) out_raw_f32[idx[i]] = raw[i];
-        if (out_log10)
-            for (size_t i = 0; i < k; ++i) out_log10[idx[i]] = l10[i];
-        return PHMM_OK;
-    });
-    if (rc != PHMM_OK) return rc;
-    if (stats) {
-        *stats = phmm_stats{};
-        for (size_t g = 0; g < n; ++g) {
-            stats->cells += st[g].cells;
-            stats->n_rescued += st[g].n_rescued;
-            stats->kernel_ms = std::max(stats->kernel_ms, st[g].kernel_ms);
-            stats->n_launches += st[g].n_launches;
-            stats->max_rows_per_lane = std::max(stats->max_rows_per_lane, st[g].max_rows_per_lane);
-        }
-    }
-    return PHMM_OK;
-}
-
-int phmm_multi_compute(phmm_multi *m, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats)
-{
-    if (!m || !b) return fail(PHMM_E_INVALID, "phmm_multi_compute: null argument");
-    const auto t0 = std::chrono::steady_clock::now();
-    phmm_multi_resident part;  // only the cut lives here; every device computes through its context's own scratch batch
-    int rc = partition_equal_cells(b, m->ctx.size(), &part);
-    if (rc != PHMM_OK) return rc;
-    const size_t n = m->ctx.size();
-    std::vector<phmm_stats> st(n);
-    rc = on_every_device(m, [&](size_t g) -> int {
-        SliceTables t;
-        slice_of(b, &part, g, t);
-        const size_t k = part.index[g].size();
-        std::vector<float> raw(out_raw_f32 ? k : 0);
-        std::vector<double> l10(out_log10 ? k : 0);
-        const int r = impl::phmm_compute(m->ctx[g], &t.view, out_raw_f32 ? raw.data() : nullptr, out_log10 ? l10.data() : nullptr, &st[g]);
-        if (r != PHMM_OK) return r;
-        const uint32_t *idx = part.index[g].data();
-        if (out_raw_f32)
-            for (size_t i = 0; i < k; ++i) out_raw_f32[idx[i]] = raw[i];
-        if (out_log10)
-            for (size_t i = 0; i < k; ++i) out_log10[idx[i]] = l10[i];
-        return PHMM_OK;
-    });
-    if (rc != PHMM_OK) return rc;
-    if (stats) {
-        *stats = phmm_stats{};
-        for (size_t g = 0; g < n; ++g) {
-            stats->cells += st[g].cells;
-            stats->n_rescued += st[g].n_rescued;
-            stats->kernel_ms = std::max(stats->kernel_ms, st[g].kernel_ms);
-            stats->n_launches += st[g].n_launches;
-            stats->max_rows_per_lane = std::max(stats->max_rows_per_lane, st[g].max_rows_per_lane);
-        }
-        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
-    return PHMM_OK;
-}
-
 // ---- allele marginalisation ----
 int phmm_marginalize(phmm_context *c, const double *old, uint32_t n_old, uint32_t stride, uint32_t evidence_count,
                      const int32_t *old2new, uint32_t n_new, double *out, double *device_ms)
@@ -1859,29 +1023,6 @@ int phmm_marginalize(phmm_context *c, const double *old, uint32_t n_old, uint32_
 }
 
 }  // namespace impl
-
-// ----------------------------------------------------------------------------------------------------
-// the C boundary: nothing is thrown across it
-// ----------------------------------------------------------------------------------------------------
-namespace
-{
-template <typename F>
-int guarded(const char *what, F &&fn)
-{
-    try {
-        return fn();
-    }
-    catch (const std::bad_alloc &) {
-        return fail(PHMM_E_NOMEM, "%s: out of host memory", what);
-    }
-    catch (const std::exception &e) {
-        return fail(PHMM_E_INVALID, "%s: %s", what, e.what());
-    }
-    catch (...) {
-        return fail(PHMM_E_INVALID, "%s: unexpected exception", what);
-    }
-}
-}  // namespace
 
 extern "C" {
 
@@ -2012,69 +1153,6 @@ int phmm_marginalize(phmm_context *c, const double *old, uint32_t n_old, uint32_
                      uint32_t n_new, double *out, double *device_ms)
 {
     return guarded("phmm_marginalize", [&] { return impl::phmm_marginalize(c, old, n_old, stride, evidence_count, old2new, n_new, out, device_ms); });
-}
-
-int phmm_create_multi(const int *device_ids, int n, phmm_multi **out)
-{
-    return guarded("phmm_create_multi", [&] { return impl::phmm_create_multi(device_ids, n, out); });
-}
-int phmm_create_multi_cpu(int n_slices, int n_threads_each, int allow_simd, phmm_multi **out)
-{
-    return guarded("phmm_create_multi_cpu", [&] { return impl::phmm_create_multi_cpu(n_slices, n_threads_each, allow_simd, out); });
-}
-void phmm_destroy_multi(phmm_multi *m)
-{
-    (void)guarded("phmm_destroy_multi", [&] { impl::phmm_destroy_multi(m); return PHMM_OK; });
-}
-int phmm_multi_device_count(const phmm_multi *m) { return m ? (int)m->ctx.size() : 0; }
-int phmm_multi_device_id(const phmm_multi *m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[i]->device : -1; }
-int phmm_multi_compute(phmm_multi *m, const phmm_batch *b, float *raw, double *l10, phmm_stats *st)
-{
-    return guarded("phmm_multi_compute", [&] { return impl::phmm_multi_compute(m, b, raw, l10, st); });
-}
-int phmm_multi_upload(phmm_multi *m, const phmm_batch *b, phmm_multi_resident **out)
-{
-    return guarded("phmm_multi_upload", [&] { return impl::phmm_multi_upload(m, b, out); });
-}
-int phmm_multi_sweep(phmm_multi *m, phmm_multi_resident *rb) { return guarded("phmm_multi_sweep", [&] { return impl::phmm_multi_sweep(m, rb); }); }
-int phmm_multi_synchronize(phmm_multi *m) { return guarded("phmm_multi_synchronize", [&] { return impl::phmm_multi_synchronize(m); }); }
-int phmm_multi_sweep_timed(phmm_multi *m, phmm_multi_resident *rb, int iters, double *wall_ms, double *dev_ms, double *f32_ms)
-{
-    return guarded("phmm_multi_sweep_timed", [&] { return impl::phmm_multi_sweep_timed(m, rb, iters, wall_ms, dev_ms, f32_ms); });
-}
-int phmm_multi_download(phmm_multi *m, phmm_multi_resident *rb, float *raw, double *l10, phmm_stats *st)
-{
-    return guarded("phmm_multi_download", [&] { return impl::phmm_multi_download(m, rb, raw, l10, st); });
-}
-int phmm_plan_slices(const phmm_batch *b, int n_slices, uint32_t *slice_of_pair, uint64_t *cells)
-{
-    // the cut alone, no device involved: lets the N > 1 path be checked on a machine without GPUs
-    return guarded("phmm_plan_slices", [&]() -> int {
-        if (!b || n_slices < 1) return fail(PHMM_E_INVALID, "phmm_plan_slices: bad arguments");
-        phmm_multi_resident plan;
-        const int rc = impl::partition_equal_cells(b, (size_t)n_slices, &plan);
-        if (rc != PHMM_OK) return rc;
-        for (int g = 0; g < n_slices; ++g) {
-            if (cells) cells[g] = plan.cells[g];
-            if (slice_of_pair)
-                for (uint32_t p : plan.index[g]) slice_of_pair[p] = (uint32_t)g;
-        }
-        return PHMM_OK;
-    });
-}
-
-int phmm_multi_shard_cells(const phmm_multi_resident *rb, uint64_t *cells, uint64_t *pairs)
-{
-    if (!rb) return fail(PHMM_E_INVALID, "phmm_multi_shard_cells: null argument");
-    for (size_t g = 0; g < rb->cells.size(); ++g) {
-        if (cells) cells[g] = rb->cells[g];
-        if (pairs) pairs[g] = rb->index[g].size();
-    }
-    return PHMM_OK;
-}
-void phmm_multi_release(phmm_multi *m, phmm_multi_resident *rb)
-{
-    (void)guarded("phmm_multi_release", [&] { impl::phmm_multi_release(m, rb); return PHMM_OK; });
 }
 
 }  // extern "C"

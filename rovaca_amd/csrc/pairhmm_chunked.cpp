@@ -1,0 +1,390 @@
+// pairhmm_chunked.cpp -- the one-shot call (phmm_compute: host buffers in, host buffers out) on a BIG batch: the pair list is cut into
+// chunks that go through three resident slots as a two-thread pipeline, so that binning, packing and upload of one chunk, the sweep of
+// the one before and the host conversion of the one before that overlap.  SURVEY.md 8(d)'s PCIe-inclusive metric is this path.
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+
+#include "pairhmm_engine.h"
+
+using phmm_detail::g_err;
+
+namespace impl
+{
+
+// ---- the chunked one-shot call ----
+
+constexpr uint64_t kChunkTargetPairs = 1u << 17;
+constexpr unsigned kMaxChunks = 8;
+
+// Cuts the pair list into contiguous chunks and finds each chunk's table windows.  Returns false when chunking would not
+// pay: a small batch, or a pair list that jumps around the tables so that the windows overlap heavily (each chunk would
+// upload most of the tables again).
+bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
+{
+    const bool cross = b->pair_read == nullptr;
+    const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
+    if (n < kChunkedMinPairs || b->n_reads == 0 || b->n_haps == 0) return false;
+    if (const char *e = phmm_hook("PHMM_NO_CHUNKED_COMPUTE")) {  // tests
+        if (e[0] != '0') return false;
+    }
+    // Chunk sizes rise and fall: the first chunk's packing and the last chunk's conversion are the only host work the device
+    // cannot hide, so those two are small -- 2 % and 8 % of the batch from seven chunks on.
+    unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(2, n / kChunkTargetPairs + 2));
+    std::vector<unsigned> weight(C);
+    for (unsigned k = 0; k < C; ++k) weight[k] = std::min(k + 1, std::min(C - k, 3u));
+    if (C >= 7) {
+        // percent of the batch.  Packing is ~2.6x faster than sweeping, so a chunk may be up to 2.6x the one before it without the
+        // device running dry; the first is as small as a launch can usefully be, the last small enough for a short conversion tail
+        static const unsigned graded[] = {2, 6, 14, 26, 26, 18, 8};
+        C = 7;
+        weight.assign(graded, graded + 7);
+    }
+    if (const char *e = phmm_hook("PHMM_CHUNK_WEIGHTS")) {  // tuning aid: relative chunk sizes, e.g. "1,2,3,2,1"
+        std::vector<unsigned> w;
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const unsigned long v = strtoul(q, &end, 10);
+            if (end == q) break;
+            if (v) w.push_back((unsigned)std::min<unsigned long>(v, 1000));
+            q = *end ? end + 1 : end;
+        }
+        if (w.size() >= 2 && w.size() <= 16) {
+            weight = w;
+            C = (unsigned)w.size();
+        }
+    }
+    std::vector<uint64_t> cut(C + 1, 0);
+    {
+        uint64_t wsum = 0, run = 0;
+        for (unsigned k = 0; k < C; ++k) wsum += weight[k];
+        for (unsigned k = 0; k < C; ++k) {
+            run += weight[k];
+            cut[k + 1] = cross ? (uint64_t)b->n_reads * run / wsum : n * run / wsum;
+        }
+    }
+    plan.assign(C, ChunkWindow());
+    std::atomic<bool> bad{false};
+    parallel_ranges(C, std::min(C, host_threads()), [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t k = lo; k < hi; ++k) {
+            ChunkWindow &w = plan[k];
+            if (cross) {
+                w.r0 = (uint32_t)cut[k];
+                w.r1 = (uint32_t)cut[k + 1];
+                w.p0 = (uint64_t)w.r0 * b->n_haps;
+                w.p1 = (uint64_t)w.r1 * b->n_haps;
+                w.h0 = 0;
+                w.h1 = b->n_haps;
+            }
+            else {
+                w.p0 = cut[k];
+                w.p1 = cut[k + 1];
+                uint32_t rmin = UINT32_MAX, rmax = 0, hmin = UINT32_MAX, hmax = 0;
+                for (uint64_t p = w.p0; p < w.p1; ++p) {
+                    const uint32_t r = b->pair_read[p], h = b->pair_hap[p];
+                    rmin = std::min(rmin, r);
+                    rmax = std::max(rmax, r);
+                    hmin = std::min(hmin, h);
+                    hmax = std::max(hmax, h);
+                }
+                if (w.p1 == w.p0 || rmax >= b->n_reads || hmax >= b->n_haps) {
+                    bad.store(true);  // empty chunk or an index out of range: let the plain path report it
+                    return;
+                }
+                w.r0 = rmin;
+                w.r1 = rmax + 1;
+                w.h0 = hmin;
+                w.h1 = hmax + 1;
+            }
+            uint64_t lo_b = UINT64_MAX, hi_b = 0;
+            for (uint32_t r = w.r0; r < w.r1; ++r) {
+                lo_b = std::min<uint64_t>(lo_b, b->read_off[r]);
+                hi_b = std::max<uint64_t>(hi_b, (uint64_t)b->read_off[r] + b->read_len[r]);
+            }
+            w.rb0 = w.r1 > w.r0 ? lo_b : 0;
+            w.rb1 = w.r1 > w.r0 ? hi_b : 0;
+            lo_b = UINT64_MAX;
+            hi_b = 0;
+            for (uint32_t h = w.h0; h < w.h1; ++h) {
+                lo_b = std::min<uint64_t>(lo_b, b->hap_off[h]);
+                hi_b = std::max<uint64_t>(hi_b, (uint64_t)b->hap_off[h] + b->hap_len[h]);
+            }
+            w.hb0 = w.h1 > w.h0 ? lo_b : 0;
+            w.hb1 = w.h1 > w.h0 ? hi_b : 0;
+        }
+    });
+    if (bad.load()) return false;
+    uint64_t win_bytes = 0, all_lo = UINT64_MAX, all_hi = 0, hall_lo = UINT64_MAX, hall_hi = 0;
+    for (const ChunkWindow &w : plan) {
+        if (w.p1 == w.p0) return false;
+        win_bytes += 5 * (w.rb1 - w.rb0) + (w.hb1 - w.hb0);
+        all_lo = std::min(all_lo, w.rb0);
+        all_hi = std::max(all_hi, w.rb1);
+        hall_lo = std::min(hall_lo, w.hb0);
+        hall_hi = std::max(hall_hi, w.hb1);
+    }
+    const uint64_t once = 5 * (all_hi - all_lo) + (hall_hi - hall_lo);
+    return win_bytes <= once + once / 2 + (1u << 20);
+}
+
+// The chunked one-shot call as a two-thread pipeline.  The calling thread bins, packs and enqueues chunk after chunk without ever
+// waiting for the device (upload + set-up on the upload stream, the sweep behind an event on the context's stream, the result
+// copy behind another event on the download stream, so that the next sweep starts the moment this one ends); a collector thread
+// takes the chunks in order as their results arrive, fetches the fp64 sums where anything was rescued, and does the host log10.
+// Three resident slots: chunk k is packed while k - 1 is swept and k - 2 is being converted.  The device queue stays non-empty
+// from the first chunk's sweep to the last one's -- round 2 packed chunk k + 1 only after chunk k - 1 had been collected, and the
+// sweeps of one call took 10.0 ms for 8.3 ms of work because the clock ramped down in the gaps.
+int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<ChunkWindow> &plan, float *out_raw_f32,
+                           double *out_log10, phmm_stats *stats)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    constexpr int S = phmm_context::kChunkSlots;
+    for (int i = 0; i < S; ++i) {
+        if (!c->chunk_slot[i]) {
+            c->chunk_slot[i] = new (std::nothrow) phmm_resident();
+            if (!c->chunk_slot[i]) return fail(PHMM_E_NOMEM, "phmm_compute: out of host memory");
+        }
+        if (!c->chunk_up[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_up[i], hipEventDisableTiming));
+        if (!c->chunk_swept[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_swept[i], hipEventDisableTiming));
+        if (!c->chunk_done[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming));
+    }
+    if (!c->down) HIP_TRY(hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking));
+    hipStream_t up = c->side[phmm_context::kSideStreams - 1];  // not used by the sweeps (n_side defaults to 2 of 3)
+    if (c->n_side >= phmm_context::kSideStreams) up = c->stream;
+    hipStream_t down = c->down;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // nothing of an earlier call still reads the slots
+    if (up != c->stream) HIP_TRY(hipStreamSynchronize(up));
+    HIP_TRY(hipStreamSynchronize(down));
+    const bool cross = b->pair_read == nullptr;
+    const size_t n_chunks = plan.size();
+    const bool trace = getenv("PHMM_PHASE_TIMING") != nullptr;  // tuning aid: host time line of the pipeline on stderr
+    const bool direct = phmm_hook("PHMM_CHUNK_RESULTS_BY_COPY") == nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+
+    struct InFlight
+    {
+        const ChunkWindow *w = nullptr;
+        size_t count_at = 0;
+    } fl[S];
+    // hand-off between the two threads: chunks [0, enqueued) are on the device, [0, collected) are finished
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t enqueued = 0, collected = 0;
+    bool producer_failed = false;
+    int collector_rc = PHMM_OK;
+    std::string collector_msg;
+    phmm_stats total{};
+
+    auto collect = [&](size_t k) -> int {
+        const int slot = (int)(k % S);
+        phmm_resident *rb = c->chunk_slot[slot];
+        const ChunkWindow &w = *fl[slot].w;
+        const uint64_t n = rb->n_pairs;
+        HIP_TRY(hipEventSynchronize(c->chunk_done[slot]));
+        const double t_ready = trace ? now_us() : 0.0;
+        const size_t off_cnt = fl[slot].count_at * sizeof(float), off64 = off_cnt + 256;
+        const uint8_t *st = static_cast<const uint8_t *>(rb->out_stage.p);
+        const float *rp = reinterpret_cast<const float *>(st);
+        const double *r64 = reinterpret_cast<const double *>(st + off64);
+        bool want64 = true;  // results written by the kernels straight into the pinned stage: the fp64 sums are there already
+        if (!direct) {
+            const uint32_t *counts = reinterpret_cast<const uint32_t *>(st + off_cnt);
+            rb->last_rescued = 0;
+            for (int qi = 0; qi < kQueues; ++qi) rb->last_rescued += counts[qi];
+            want64 = out_log10 && rb->last_rescued;
+            if (want64) {
+                // the rescue kernels of this chunk are done (the event above follows them); the copy runs beside the next sweep
+                HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(st) + off64, rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, down));
+                HIP_TRY(hipStreamSynchronize(down));
+            }
+        }
+        if (out_raw_f32) memcpy(out_raw_f32 + w.p0, rp, n * sizeof(float));
+        std::atomic<uint64_t> n_resc{0};
+        {
+            double *dst = out_log10 ? out_log10 + w.p0 : nullptr;
+            auto finalize = [&](uint64_t lo, uint64_t hi, unsigned) {  // pairhmm_internal.cpp:577-585
+                uint64_t resc = 0;
+                for (uint64_t p = lo; p < hi; ++p) {
+                    const float x = rp[p];
+                    if (x < PHMM_MIN_ACCEPTED_F32) {
+                        ++resc;
+                        if (dst) dst[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
+                    }
+                    else if (dst) {
+                        dst[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
+                    }
+                }
+                n_resc.fetch_add(resc, std::memory_order_relaxed);
+            };
+            if (n >= (1u << 14))
+                parallel_ranges(n, c->fin_pool->helpers() + 1u, finalize);
+            else
+                finalize(0, n, 0);
+        }
+        rb->last_rescued = (uint32_t)n_resc.load();
+        total.cells += rb->cells;
+        total.n_rescued += rb->last_rescued;
+        total.n_launches += (uint32_t)rb->bins.size();
+        if (!rb->bins.empty()) total.max_rows_per_lane = std::max<uint32_t>(total.max_rows_per_lane, (uint32_t)rb->bins.back().rows_per_lane);
+        if (trace) fprintf(stderr, "phmm chunk %zu: results on the host at %.0f us, converted at %.0f us\n", k, t_ready, now_us());
+        return PHMM_OK;
+    };
+
+    std::thread collector([&] {
+        (void)hipSetDevice(c->device);
+        phmm_detail::PoolScope pool(c->fin_pool);
+        for (size_t k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return enqueued > k || producer_failed; });
+                if (enqueued <= k) return;  // the producer gave up before this chunk
+            }
+            int rc = PHMM_OK;
+            try {
+                rc = collect(k);
+            }
+            catch (...) {
+                rc = fail(PHMM_E_NOMEM, "phmm_compute: the collector thread ran out of memory");
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc != PHMM_OK && collector_rc == PHMM_OK) {
+                    collector_rc = rc;
+                    collector_msg = g_err;  // (thread-local: carry the text over)
+                }
+                collected = k + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    struct Joiner  // whichever way this function returns, the collector is told and joined first
+    {
+        std::thread &t;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &failed;
+        bool ok = false;
+        ~Joiner()
+        {
+            if (!ok) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    failed = true;
+                }
+                cv.notify_all();
+            }
+            t.join();
+        }
+    } joiner{collector, mu, cv, producer_failed};
+
+    phmm_detail::PoolScope pool(c->pack_pool);
+    std::vector<uint32_t> roff, hoff;
+    for (size_t k = 0; k < n_chunks; ++k) {
+        const ChunkWindow &w = plan[k];
+        const int slot = (int)(k % S);
+        if (k >= (size_t)S) {  // the slot held chunk k - S: its results must have left it
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return collected + S > k; });
+            if (collector_rc != PHMM_OK) break;
+        }
+        const double t_a = trace ? now_us() : 0.0;
+        phmm_resident *rb = c->chunk_slot[slot];
+        // the chunk as a batch of its own: windows of the tables, offsets rebased to the windows, pair indices biased
+        phmm_batch s = *b;
+        s.n_reads = w.r1 - w.r0;
+        s.n_haps = w.h1 - w.h0;
+        s.n_pairs = w.p1 - w.p0;
+        roff.resize(s.n_reads);
+        for (uint32_t r = 0; r < s.n_reads; ++r) roff[r] = (uint32_t)(b->read_off[w.r0 + r] - w.rb0);
+        hoff.resize(s.n_haps);
+        for (uint32_t h = 0; h < s.n_haps; ++h) hoff[h] = (uint32_t)(b->hap_off[w.h0 + h] - w.hb0);
+        s.read_bases = b->read_bases + w.rb0;
+        s.read_qual = b->read_qual + w.rb0;
+        s.read_ins = b->read_ins ? b->read_ins + w.rb0 : nullptr;
+        s.read_del = b->read_del ? b->read_del + w.rb0 : nullptr;
+        s.read_gcp = b->read_gcp ? b->read_gcp + w.rb0 : nullptr;
+        s.read_off = roff.data();
+        s.read_len = b->read_len + w.r0;
+        s.hap_bases = b->hap_bases + w.hb0;
+        s.hap_off = hoff.data();
+        s.hap_len = b->hap_len + w.h0;
+        s.pair_read = cross ? nullptr : b->pair_read + w.p0;
+        s.pair_hap = cross ? nullptr : b->pair_hap + w.p0;
+        phmm_read_prep prep_k;
+        if (b->prep) {
+            prep_k = *b->prep;
+            prep_k.read_mapq = b->prep->read_mapq ? b->prep->read_mapq + w.r0 : nullptr;
+            s.prep = &prep_k;
+        }
+        UploadOpts opt;
+        opt.stream = up;
+        opt.caller_synchronised = true;  // slot `slot` held chunk k - S: collected (see above), so its sweep is long over
+        opt.read_bias = cross ? 0 : w.r0;
+        opt.hap_bias = cross ? 0 : w.h0;
+        // The copy travels on the upload stream (DMA engines: it runs beside the previous chunk's sweep); the set-up launch goes on
+        // the context's stream, in front of this chunk's sweep.  On the upload stream it would not start before the previous sweep
+        // has handed out its last workgroup -- small kernels of another queue are starved by a grid that fills the chip -- and the
+        // sweep behind it would wait with it: 90-110 us of a drained chip at every chunk boundary (rocprofv3 time line, round 3).
+        opt.setup_stream = c->stream;
+        if (k == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        PhaseClock chunk_clock;
+        struct PhaseScope
+        {
+            explicit PhaseScope(PhaseClock *p) { g_phase = p; }
+            ~PhaseScope() { g_phase = nullptr; }
+        } phase_scope(trace ? &chunk_clock : nullptr);
+        int rc = upload_into(c, &s, rb, opt);
+        if (rc != PHMM_OK) return rc;
+        // where the sums go: straight into the slot's pinned result block (the kernels write host memory over PCIe: no copy, no
+        // cross-stream event between two sweeps), or -- PHMM_CHUNK_RESULTS_BY_COPY=1 -- into HBM and from there by a copy
+        const uint64_t n = rb->n_pairs;
+        const size_t count_at = (n + 63) & ~size_t(63);
+        HIP_TRY(rb->out_stage.ensure(count_at * sizeof(float) + 256 + n * sizeof(double)));
+        rb->out32_host = direct ? static_cast<float *>(rb->out_stage.p) : nullptr;
+        rb->out64_host = direct ? reinterpret_cast<double *>(static_cast<uint8_t *>(rb->out_stage.p) + count_at * sizeof(float) + 256) : nullptr;
+        rc = impl::phmm_sweep(c, rb);
+        if (rc != PHMM_OK) return rc;
+        PHASE(4);
+        if (k + 1 == n_chunks) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        if (direct) {
+            HIP_TRY(hipEventRecord(c->chunk_done[slot], c->stream));
+        }
+        else {
+            // the sums travel on the download stream: the next chunk's sweep does not queue behind the copy
+            HIP_TRY(hipEventRecord(c->chunk_swept[slot], c->stream));
+            HIP_TRY(hipStreamWaitEvent(down, c->chunk_swept[slot], 0));
+            HIP_TRY(hipMemcpyAsync(rb->out_stage.p, rb->raw32.p, count_at * sizeof(float) + kQueues * sizeof(uint32_t), hipMemcpyDeviceToHost, down));
+            HIP_TRY(hipEventRecord(c->chunk_done[slot], down));
+        }
+        fl[slot].w = &w;
+        fl[slot].count_at = count_at;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            enqueued = k + 1;
+        }
+        cv.notify_all();
+        if (trace) {
+            PHASE(5);
+            fprintf(stderr, "phmm chunk %zu: %llu pairs, packed and enqueued %.0f..%.0f us (validate %.0f pack %.0f bin %.0f copy+setup %.0f sweep-enqueue %.0f results-enqueue %.0f)\n",
+                    k, (unsigned long long)(w.p1 - w.p0), t_a, now_us(), chunk_clock.us[0], chunk_clock.us[1], chunk_clock.us[2], chunk_clock.us[3],
+                    chunk_clock.us[4], chunk_clock.us[5]);
+        }
+    }
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return collected >= enqueued || collector_rc != PHMM_OK; });
+    }
+    joiner.ok = enqueued == n_chunks;
+    if (collector_rc != PHMM_OK) return fail(collector_rc, "%s", collector_msg.c_str());
+    if (enqueued != n_chunks) return fail(PHMM_E_INVALID, "phmm_compute: the chunk pipeline stopped early");
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        total.kernel_ms = ms;
+        *stats = total;
+    }
+    return PHMM_OK;
+}
+
+}  // namespace impl

@@ -8,7 +8,11 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -222,6 +226,65 @@ struct phmm_resident
 };
 
 
+// PHMM_PHASE_TIMING=1: host phases of phmm_compute on stderr (tuning aid)
+struct PhaseClock
+{
+    bool on = getenv("PHMM_PHASE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    double us[8] = {0};
+    void lap(int i)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        us[i] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+};
+extern thread_local PhaseClock *g_phase;  // pairhmm_capi.cpp
+#define PHASE(i) do { if (g_phase) g_phase->lap(i); } while (0)
+
+// How a batch reaches the device.  The defaults are the plain upload; the chunked one-shot call (phmm_compute on a big batch)
+// uploads on a side stream without waiting for the context's stream, and hands in windows of the tables with the pair
+// indices still counted from the start of the caller's tables.
+struct UploadOpts
+{
+    hipStream_t stream = nullptr;  // the copy; null: the context's stream
+    hipStream_t setup_stream = nullptr;  // the fill and the set-up launch; null: the stream of the copy
+    bool caller_synchronised = false;  // the caller knows that nothing on the device still reads this resident's buffers
+    uint32_t read_bias = 0, hap_bias = 0;  // subtracted from pair_read / pair_hap
+};
+
+// A window of the caller's tables that holds everything a contiguous range of the pair list refers to (pairhmm_chunked.cpp).
+struct ChunkWindow
+{
+    uint64_t p0 = 0, p1 = 0;               // pairs
+    uint32_t r0 = 0, r1 = 0, h0 = 0, h1 = 0;  // reads [r0, r1), haplotypes [h0, h1)
+    uint64_t rb0 = 0, rb1 = 0, hb0 = 0, hb1 = 0;  // byte ranges of the two tables
+};
+constexpr uint64_t kChunkedMinPairs = 1u << 19;  // below this one upload + one sweep is as fast
+
+namespace phmm_detail
+{
+// the C boundary: nothing is thrown across it (every extern "C" entry point runs its body through this)
+template <typename F>
+int guarded(const char *what, F &&fn)
+{
+    try {
+        return fn();
+    }
+    catch (const std::bad_alloc &) {
+        return fail(PHMM_E_NOMEM, "%s: out of host memory", what);
+    }
+    catch (const std::exception &e) {
+        return fail(PHMM_E_INVALID, "%s: %s", what, e.what());
+    }
+    catch (...) {
+        return fail(PHMM_E_INVALID, "%s: unexpected exception", what);
+    }
+}
+}  // namespace phmm_detail
+using phmm_detail::guarded;
+
 // The entry points are implemented in this namespace with C++ linkage; the extern "C" wrappers at the end of pairhmm_capi.cpp
 // catch whatever a body may throw, so that nothing crosses the C boundary.
 namespace impl
@@ -232,6 +295,20 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb);
 int cpu_upload(phmm_context *c, const phmm_batch *b, phmm_resident *rb);
 int cpu_sweep(phmm_context *c, phmm_resident *rb);
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats);
+int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt);  // bin, pack, copy, set-up launch
+int phmm_create(int device_id, void *stream, phmm_context **out);
+int phmm_create_cpu(int n_threads, int allow_simd, phmm_context **out);
+void phmm_destroy(phmm_context *c);
+int phmm_synchronize(phmm_context *c);
+int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out);
+int phmm_sweep(phmm_context *c, phmm_resident *rb);
+int phmm_sweep_timed(phmm_context *c, phmm_resident *rb, int iters, double *ms_per_pass, double *fp32_ms_per_pass);
+int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double *out_log10, phmm_stats *stats);
+void phmm_release(phmm_context *c, phmm_resident *rb);
+// pairhmm_chunked.cpp: the one-shot call on a big batch as a pipeline of chunks
+bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan);
+int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<ChunkWindow> &plan, float *out_raw_f32, double *out_log10,
+                    phmm_stats *stats);
 // pairhmm_stage.cpp
 int phmm_stage_create(phmm_context *c, const phmm_stage_caps *caps, phmm_stage **out);
 void phmm_stage_destroy(phmm_context *c, phmm_stage *st);

@@ -182,4 +182,4 @@ int main(void)
         assert r.returncode == 0, r.stderr
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
-        assert out.stdout.split() == ["4", "1", str(ctypes.sizeof(capi.PhmmBatch))]
+        assert out.stdout.split() == ["5", "1", str(ctypes.sizeof(capi.PhmmBatch))]

@@ -8,6 +8,6 @@ cd "$(dirname "$0")/../rovaca_amd/csrc"
 OUT=../lib; V=$OUT/variants; mkdir -p $V
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fgpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c pairhmm_kernels.hip -o $V/kernels_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/lib_$NAME.so $V/kernels_$NAME.o $OUT/pairhmm_setup.o $OUT/pairhmm_capi.o $OUT/pairhmm_stage.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/lib_$NAME.so $V/kernels_$NAME.o $OUT/pairhmm_setup.o $OUT/pairhmm_capi.o $OUT/pairhmm_chunked.o $OUT/pairhmm_multi.o $OUT/pairhmm_stage.o \
     $OUT/pairhmm_binning.o $OUT/pairhmm_tables.o $OUT/pairhmm_marginal.o $OUT/pairhmm_cpu.o $OUT/pairhmm_host_logic.o -lpthread
 echo "$V/lib_$NAME.so"
