@@ -11,7 +11,12 @@
 #include <mutex>
 #include <thread>
 
+#include <climits>
+#include <linux/futex.h>
 #include <pthread.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <vector>
 
 #include "../../include/smithwaterman_hip.h"
 
@@ -60,65 +65,101 @@ namespace
 using rovaca::SwAlignment;
 using rovaca::SwJob;
 
-// one device call for `n` jobs on the calling thread's context
-bool align_now(const SwJob *jobs, size_t n, const sw_parameters &para, SwAlignment *out)
+// reusable host buffers of one device call (per calling thread: a dispatcher, or a worker on the unbatched path)
+struct CallBuffers
 {
-    if (n == 0) return true;
     std::vector<uint8_t> refs, seqs;
-    std::vector<uint32_t> roff(n), rlen(n), soff(n), slen(n), idx(n);
+    std::vector<uint32_t> roff, rlen, soff, slen, idx;
+    std::vector<swhip_alignment> res;
+    std::vector<uint32_t> cigars;
+};
+
+// one device call for `n` jobs on the calling thread's context; results in buf.res / buf.cigars (cigar_off indexes buf.cigars)
+bool align_raw(const SwJob *jobs, size_t n, const sw_parameters &para, CallBuffers &buf)
+{
+    buf.refs.clear();
+    buf.seqs.clear();
+    buf.roff.resize(n);
+    buf.rlen.resize(n);
+    buf.soff.resize(n);
+    buf.slen.resize(n);
+    buf.idx.resize(n);
     size_t cap = 0;
     for (size_t k = 0; k < n; ++k) {
-        roff[k] = (uint32_t)refs.size();
-        rlen[k] = (uint32_t)jobs[k].ref_len;
-        refs.insert(refs.end(), jobs[k].ref, jobs[k].ref + jobs[k].ref_len);
-        soff[k] = (uint32_t)seqs.size();
-        slen[k] = (uint32_t)jobs[k].seq_len;
-        seqs.insert(seqs.end(), jobs[k].seq, jobs[k].seq + jobs[k].seq_len);
-        idx[k] = (uint32_t)k;
+        buf.roff[k] = (uint32_t)buf.refs.size();
+        buf.rlen[k] = (uint32_t)jobs[k].ref_len;
+        buf.refs.insert(buf.refs.end(), jobs[k].ref, jobs[k].ref + jobs[k].ref_len);
+        buf.soff[k] = (uint32_t)buf.seqs.size();
+        buf.slen[k] = (uint32_t)jobs[k].seq_len;
+        buf.seqs.insert(buf.seqs.end(), jobs[k].seq, jobs[k].seq + jobs[k].seq_len);
+        buf.idx[k] = (uint32_t)k;
         cap += (size_t)jobs[k].ref_len + (size_t)jobs[k].seq_len + 2;
     }
     swhip_batch b{};
     b.n_refs = b.n_seqs = (uint32_t)n;
     b.n_pairs = n;
-    b.ref_bases = refs.data();
-    b.ref_off = roff.data();
-    b.ref_len = rlen.data();
-    b.seq_bases = seqs.data();
-    b.seq_off = soff.data();
-    b.seq_len = slen.data();
-    b.pair_ref = idx.data();
-    b.pair_seq = idx.data();
+    b.ref_bases = buf.refs.data();
+    b.ref_off = buf.roff.data();
+    b.ref_len = buf.rlen.data();
+    b.seq_bases = buf.seqs.data();
+    b.seq_off = buf.soff.data();
+    b.seq_len = buf.slen.data();
+    b.pair_ref = buf.idx.data();
+    b.pair_seq = buf.idx.data();
     const swhip_params prm{para.match, para.mismatch, para.gap_open, para.gap_extend};
-    std::vector<swhip_alignment> res(n);
-    std::vector<uint32_t> cigars(cap);
+    buf.res.resize(n);
+    if (buf.cigars.size() < cap) buf.cigars.resize(cap);
     uint64_t used = 0;
-    if (swhip_align(t_ctx.get(), &prm, &b, res.data(), cigars.data(), cap, &used, nullptr) != SWHIP_OK) {
+    if (swhip_align(t_ctx.get(), &prm, &b, buf.res.data(), buf.cigars.data(), cap, &used, nullptr) != SWHIP_OK) {
         fprintf(stderr, "[rovaca_amd] smith-waterman: %s\n", swhip_last_error());
         return false;
     }
+    return true;
+}
+
+// what the seam hands back, from the flat results of a call (run by the thread that asked: the per-alignment vectors are its allocations)
+void unpack(const swhip_alignment *res, const uint32_t *cigars, size_t n, SwAlignment *out)
+{
     for (size_t k = 0; k < n; ++k) {
         out[k].score = res[k].score;
         out[k].max_i = res[k].max_i;
         out[k].max_j = res[k].max_j;
         out[k].alignment_offset = res[k].alignment_offset;
         out[k].too_long = res[k].too_long != 0;
-        out[k].cigar.assign(cigars.begin() + res[k].cigar_off, cigars.begin() + res[k].cigar_off + res[k].cigar_count);
+        out[k].cigar.assign(cigars + res[k].cigar_off, cigars + res[k].cigar_off + res[k].cigar_count);
     }
+}
+
+bool align_now(const SwJob *jobs, size_t n, const sw_parameters &para, SwAlignment *out)
+{
+    if (n == 0) return true;
+    static thread_local CallBuffers buf;
+    if (!align_raw(jobs, n, para, buf)) return false;
+    unpack(buf.res.data(), buf.cigars.data(), n, out);
     return true;
+}
+
+static long futex_call(std::atomic<uint32_t> *addr, int op, uint32_t val)
+{
+    return syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), op, val, nullptr, nullptr, 0);
 }
 
 // Cross-region batching, as for PairHMM (pairhmm_gpu_engine.cpp): the reference's workers realign one region at a time
 // (haplotypecaller_engine.cpp:264), 48 alignments or so -- a dozen waves.  Dispatcher threads merge every request that queued
-// up while the previous device call was in flight into one call and hand each worker its slice.
-// ROVACA_AMD_SW_BATCHING=0 bypasses it (each worker calls the device itself); ROVACA_AMD_SW_DISPATCHERS sets their number (1).
+// up while the previous device call was in flight into one call.  The dispatcher's share per request is a copy of its slice of
+// the flat results (records and CIGAR elements) into buffers the request owns; the per-alignment vectors the seam returns are
+// built by the worker that asked, after it has been woken -- through a futex word of its own, so that a finished call wakes
+// exactly the workers it served.  ROVACA_AMD_SW_BATCHING=0 bypasses it (each worker calls the device itself);
+// ROVACA_AMD_SW_DISPATCHERS sets their number.
 struct Request
 {
-    const SwJob *jobs;
-    size_t n;
-    sw_parameters para;
-    SwAlignment *out;
+    const SwJob *jobs = nullptr;
+    size_t n = 0;
+    sw_parameters para{};
+    std::vector<swhip_alignment> res;  // [n], cigar_off rebased to `cigars`
+    std::vector<uint32_t> cigars;
     bool ok = true;
-    std::atomic<bool> done{false};
+    std::atomic<uint32_t> done{0};     // futex word
 };
 
 class SwBatcher
@@ -128,16 +169,17 @@ public:
     // the request (and what it points at) must stay alive until wait() has returned
     void submit(Request &rq)
     {
+        bool wake;
         {
             std::lock_guard<std::mutex> lk(mu_);
             queue_.push_back(&rq);
+            wake = sleeping_;
         }
-        cv_.notify_one();
+        if (wake) cv_.notify_one();
     }
-    bool wait(Request &rq)
+    static bool wait(Request &rq)
     {
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [&] { return rq.done.load(std::memory_order_acquire); });
+        while (rq.done.load(std::memory_order_acquire) == 0) futex_call(&rq.done, FUTEX_WAIT_PRIVATE, 0);
         return rq.ok;
     }
     bool submit_and_wait(Request &rq)
@@ -158,11 +200,13 @@ private:
         pthread_setname_np(pthread_self(), "sw-gpu-disp");
         std::vector<Request *> taken, group;
         std::vector<SwJob> jobs;
-        std::vector<SwAlignment> out;
+        CallBuffers buf;
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(mu_);
+                sleeping_ = true;
                 cv_.wait(lk, [&] { return !queue_.empty(); });
+                sleeping_ = false;
                 taken.assign(queue_.begin(), queue_.end());
                 queue_.clear();
             }
@@ -180,27 +224,39 @@ private:
                 }
                 jobs.clear();
                 for (Request *r : group) jobs.insert(jobs.end(), r->jobs, r->jobs + r->n);
-                out.assign(jobs.size(), SwAlignment{});
-                const bool ok = align_now(jobs.data(), jobs.size(), para, out.data());
+                const bool ok = align_raw(jobs.data(), jobs.size(), para, buf);
                 requests += group.size();
                 submissions += 1;
                 size_t at = 0;
                 for (Request *r : group) {
-                    for (size_t k = 0; k < r->n; ++k) r->out[k] = std::move(out[at + k]);
+                    if (ok) {
+                        // the request's slice: records as they are, CIGAR elements packed into the request's own buffer
+                        uint32_t cur = 0;
+                        for (size_t k = 0; k < r->n; ++k) {
+                            swhip_alignment a = buf.res[at + k];
+                            if (r->cigars.size() < (size_t)cur + a.cigar_count) r->cigars.resize((size_t)cur + a.cigar_count + 64);
+                            memcpy(r->cigars.data() + cur, buf.cigars.data() + a.cigar_off, (size_t)a.cigar_count * sizeof(uint32_t));
+                            a.cigar_off = cur;
+                            cur += a.cigar_count;
+                            r->res[k] = a;
+                        }
+                    }
                     at += r->n;
                     r->ok = ok;
-                    r->done.store(true, std::memory_order_release);
+                    // From the store on the request may be gone (its owner can return without ever sleeping), so nothing of it is
+                    // read again: the wake is unconditional and uses the word's address only as the kernel's key -- at worst a
+                    // spurious wake of whoever reuses that address, which every waiter tolerates.
+                    std::atomic<uint32_t> *word = &r->done;
+                    r->done.store(1);
+                    futex_call(word, FUTEX_WAKE_PRIVATE, INT32_MAX);
                 }
-                {
-                    std::lock_guard<std::mutex> lk(mu_);
-                }
-                done_cv_.notify_all();
             }
         }
     }
     std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     std::deque<Request *> queue_;
+    bool sleeping_ = false;  // guarded by mu_
     std::thread worker_;
 };
 
@@ -220,6 +276,16 @@ void start_batchers()
     for (int i = 0; i < n * devices; ++i) g_sw_batchers.push_back(new SwBatcher());
 }
 
+// a request as the worker prepares it: result slots sized, CIGAR buffer with room for the usual handful of elements per alignment
+void prepare(Request &rq, const SwJob *jobs, size_t n, const sw_parameters &para)
+{
+    rq.jobs = jobs;
+    rq.n = n;
+    rq.para = para;
+    rq.res.resize(n);
+    rq.cigars.resize(8 * n + 64);
+}
+
 }  // namespace
 
 namespace rovaca
@@ -231,17 +297,19 @@ bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, 
     if (n == 0) return true;
     std::call_once(g_sw_once, start_batchers);
     if (g_sw_batchers.empty()) return align_now(jobs, n, para, out.data());
-    Request rq{jobs, n, para, out.data()};
-    return g_sw_batchers[g_sw_next.fetch_add(1) % g_sw_batchers.size()]->submit_and_wait(rq);
+    Request rq;
+    prepare(rq, jobs, n, para);
+    if (!g_sw_batchers[g_sw_next.fetch_add(1) % g_sw_batchers.size()]->submit_and_wait(rq)) return false;
+    unpack(rq.res.data(), rq.cigars.data(), n, out.data());
+    return true;
 }
 
 // The same call in two halves, as for PairHMM (pairhmm_gpu_engine.h): begin queues the alignments and returns, finish collects.
 struct SwTicket::State
 {
     std::vector<SwJob> jobs;  // the job records are copied; the sequence bytes they point at stay the caller's
-    std::vector<SwAlignment> out;
-    sw_parameters para{};
-    Request rq{nullptr, 0, sw_parameters{}, nullptr};
+    std::vector<SwAlignment> out;  // unbatched path only
+    Request rq;
     SwBatcher *batcher = nullptr;  // null: evaluated inside begin (batching off)
     bool ok = true;
 };
@@ -252,14 +320,14 @@ SwTicket &SwTicket::operator=(SwTicket &&o) noexcept
     // assigning over a ticket whose request is still queued or on the device: its State (job records, result slots) must
     // outlive the dispatcher's writes, exactly as in the destructor
     if (this != &o) {
-        if (st_ && st_->batcher) st_->batcher->wait(st_->rq);
+        if (st_ && st_->batcher) (void)SwBatcher::wait(st_->rq);
         st_ = std::move(o.st_);
     }
     return *this;
 }
 SwTicket::~SwTicket()
 {
-    if (st_ && st_->batcher) st_->batcher->wait(st_->rq);  // dropped without finish: the dispatcher may still be writing into it
+    if (st_ && st_->batcher) (void)SwBatcher::wait(st_->rq);  // dropped without finish: the dispatcher may still be writing into it
 }
 
 SwTicket sw_hip_align_batch_begin(const SwJob *jobs, size_t n, const sw_parameters &para)
@@ -269,17 +337,13 @@ SwTicket sw_hip_align_batch_begin(const SwJob *jobs, size_t n, const sw_paramete
     t.st_.reset(new SwTicket::State());
     SwTicket::State &st = *t.st_;
     st.jobs.assign(jobs, jobs + n);
-    st.out.assign(n, SwAlignment{});
-    st.para = para;
     std::call_once(g_sw_once, start_batchers);
     if (g_sw_batchers.empty()) {
+        st.out.assign(n, SwAlignment{});
         st.ok = align_now(st.jobs.data(), n, para, st.out.data());
         return t;
     }
-    st.rq.jobs = st.jobs.data();
-    st.rq.n = n;
-    st.rq.para = para;
-    st.rq.out = st.out.data();
+    prepare(st.rq, st.jobs.data(), n, para);
     st.batcher = g_sw_batchers[g_sw_next.fetch_add(1) % g_sw_batchers.size()];
     st.batcher->submit(st.rq);
     return t;
@@ -292,8 +356,13 @@ bool sw_hip_align_batch_finish(SwTicket &&ticket, std::vector<SwAlignment> &out)
     if (!t.st_) return true;
     SwTicket::State &st = *t.st_;
     if (st.batcher) {
-        st.ok = st.batcher->wait(st.rq);
+        st.ok = SwBatcher::wait(st.rq);
         st.batcher = nullptr;
+        if (st.ok) {
+            out.assign(st.rq.n, SwAlignment{});
+            unpack(st.rq.res.data(), st.rq.cigars.data(), st.rq.n, out.data());
+        }
+        return st.ok;
     }
     out = std::move(st.out);
     return st.ok;
