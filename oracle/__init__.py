@@ -3,7 +3,8 @@
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this
 package.  ``oracle.lib()`` is the C restatement (oracle/phmm_oracle.c); ``oracle.ref()`` is the
 reference's own AVX kernels built from /root/reference into oracle/_ref/ (None when absent or when
-the host CPU lacks AVX-512).
+the host CPU lacks AVX-512).  ``oracle.f128_lib()`` is the independent __float128 statement of the
+recurrence (oracle/phmm_oracle_f128.c) that pins the fp64 rescue, whose reference kernels are defective.
 """
 import ctypes as C
 import os
