@@ -87,7 +87,7 @@ struct swhip_context
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBytes blob, bt, scratch, out, cigars;
+    DevBytes blob, bt, scratch, cigars;
     HostBytes stage, back, back_cigars;
 };
 
@@ -222,8 +222,17 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
     HIP_TRY(hipMemcpyAsync(c->blob.p, c->stage.p, total, hipMemcpyHostToDevice, st));
     HIP_TRY(c->bt.ensure(std::max(bt_peak, bt_words) * 4));
     HIP_TRY(c->scratch.ensure(scr_slots * 4));
-    HIP_TRY(c->out.ensure(n * sizeof(swhip::Alignment)));
-    HIP_TRY(c->cigars.ensure(worst_elems * 4));
+    // Results never take a copy of their own: the kernel's last lane writes each alignment's record straight into pinned host
+    // memory, and for batches whose worst-case element count is small (region-sized calls: the latency case) the CIGAR elements
+    // too.  Large batches keep the element array in HBM and fetch the part that was used.
+    const size_t res_bytes = n * sizeof(swhip::Alignment);
+    HIP_TRY(c->back.ensure(res_bytes));
+    constexpr uint64_t kDirectCigarElems = 4ull << 20;  // 16 MB of pinned memory at most
+    const bool cigars_direct = worst_elems <= kDirectCigarElems && !getenv("SWHIP_CIGARS_BY_COPY");  // (the hook: tests)
+    if (cigars_direct)
+        HIP_TRY(c->back_cigars.ensure(worst_elems * 4));
+    else
+        HIP_TRY(c->cigars.ensure(worst_elems * 4));
 
     uint8_t *base = static_cast<uint8_t *>(c->blob.p);
     swhip::SwArgs a{};
@@ -243,11 +252,11 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
     a.bt_off = reinterpret_cast<const uint64_t *>(base + o_bt);
     a.scratch = static_cast<int32_t *>(c->scratch.p);
     a.scratch_off = reinterpret_cast<const uint64_t *>(base + o_scr);
-    a.out = static_cast<swhip::Alignment *>(c->out.p);
-    a.cigars = static_cast<uint32_t *>(c->cigars.p);
+    a.out = static_cast<swhip::Alignment *>(c->back.p);
+    a.cigars = static_cast<uint32_t *>(cigars_direct ? c->back_cigars.p : c->cigars.p);
     a.cigar_cursor = reinterpret_cast<uint32_t *>(base + o_cur);
 
-    HIP_TRY(hipEventRecord(c->ev0, st));
+    if (stats) HIP_TRY(hipEventRecord(c->ev0, st));
     for (const Launch &l : launches) {
         a.order = reinterpret_cast<const uint32_t *>(base + o_order) + l.first;
         a.n_pairs = l.count;
@@ -259,21 +268,16 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
         a.lds_bt_bytes = in_lds ? (uint32_t)bt_bytes : 0u;
         HIP_TRY(swhip::launch_sw(l.k, l.lanes, a, st));
     }
-    HIP_TRY(hipEventRecord(c->ev1, st));
+    if (stats) HIP_TRY(hipEventRecord(c->ev1, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the one wait of the call
 
-    // ---- download: results + the element count, then the elements ----
-    const size_t res_bytes = n * sizeof(swhip::Alignment);
-    const size_t b_cur = (res_bytes + 255) & ~size_t(255);
-    HIP_TRY(c->back.ensure(b_cur + 256));
-    uint8_t *bp = static_cast<uint8_t *>(c->back.p);
-    HIP_TRY(hipMemcpyAsync(bp, c->out.p, res_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(bp + b_cur, a.cigar_cursor, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const uint32_t used = *reinterpret_cast<const uint32_t *>(bp + b_cur);
-    const swhip_alignment *dev_res = reinterpret_cast<const swhip_alignment *>(bp);
+    // every alignment took its elements from the cursor in one piece, so the highest end is the number used
+    const swhip_alignment *dev_res = static_cast<const swhip_alignment *>(c->back.p);
+    uint64_t used = 0;
     for (uint64_t i = 0; i < m; ++i) {
         const uint32_t p = order[i];
         out[p] = dev_res[p];
+        used = std::max<uint64_t>(used, (uint64_t)dev_res[p].cigar_off + dev_res[p].cigar_count);
     }
     *cigars_used = used;
     if (stats) {
@@ -282,14 +286,20 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
         stats->kernel_ms = ms;
         stats->n_launches = (uint32_t)launches.size();
     }
-    if (used > cigar_capacity) return fail(SWHIP_E_CAPACITY, "swhip_align: %u CIGAR elements, room for %llu", used, (unsigned long long)cigar_capacity);
+    if (used > cigar_capacity)
+        return fail(SWHIP_E_CAPACITY, "swhip_align: %llu CIGAR elements, room for %llu", (unsigned long long)used, (unsigned long long)cigar_capacity);
     if (used) {
         if (!cigars) return fail(SWHIP_E_INVALID, "swhip_align: null cigars buffer");
-        // pinned staging sized for what was produced (the worst case is sum(len1 + len2 + 2) elements)
-        HIP_TRY(c->back_cigars.ensure((size_t)used * 4));
-        HIP_TRY(hipMemcpyAsync(c->back_cigars.p, c->cigars.p, (size_t)used * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        memcpy(cigars, c->back_cigars.p, (size_t)used * 4);
+        if (cigars_direct) {
+            memcpy(cigars, c->back_cigars.p, (size_t)used * 4);
+        }
+        else {
+            // pinned staging sized for what was produced (the worst case is sum(len1 + len2 + 2) elements)
+            HIP_TRY(c->back_cigars.ensure((size_t)used * 4));
+            HIP_TRY(hipMemcpyAsync(c->back_cigars.p, c->cigars.p, (size_t)used * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            memcpy(cigars, c->back_cigars.p, (size_t)used * 4);
+        }
     }
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SWHIP_OK;

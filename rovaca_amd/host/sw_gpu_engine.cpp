@@ -269,7 +269,12 @@ void start_batchers()
     const char *on = getenv("ROVACA_AMD_SW_BATCHING");
     if (on && atoi(on) == 0) return;
     const char *nd = getenv("ROVACA_AMD_SW_DISPATCHERS");
-    int n = nd ? atoi(nd) : 1;  // one: a batch of up to ~2 000 alignments takes as long as one of 48 (lone waves), so merging wins
+    // A batch of up to ~2 000 alignments takes as long as one of 48 (lone waves), so merging is free on the device; what a second
+    // dispatcher buys is a second call in flight while the first is being unpacked.  Measured with PairHMM in front
+    // (tools/sw_adapter_sweep.sh, regions of 48 x 9, 16 host cores), 1 / 2 / 3 dispatchers: 30 synchronous workers 43.8 / 45.4 /
+    // 42.2 k regions/s, 30 workers x 4 in flight 99.6 / 122 / 112, 128 synchronous 104 / 117 / 104; 8 synchronous 17.3 / 16.3 /
+    // 13.5 and 128 x 4 (the cores are the limit there) 161 / 113 / 109.
+    int n = nd ? atoi(nd) : 2;
     n = n < 1 ? 1 : n > 16 ? 16 : n;
     // with round-robin devices every device gets its dispatchers (a dispatcher's context is created on its own thread)
     const int devices = g_sw_device.load() < 0 ? std::max(1, swhip_device_count()) : 1;
