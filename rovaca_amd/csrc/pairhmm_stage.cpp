@@ -340,7 +340,10 @@ int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint3
     rb.queue_is_empty = true;
     rc = impl::sweep_fp32(c, &rb);
     if (rc == PHMM_OK) rc = impl::sweep_rescue(c, &rb);
-    if (rc != PHMM_OK) return rc;
+    if (rc != PHMM_OK) {
+        (void)hipStreamSynchronize(c->stream);  // whatever was enqueued reads the arena and writes the stage's results: let it end
+        return rc;
+    }
     HIP_TRY(hipEventRecord(st->ev1, c->stream));
     st->in_flight = true;
     return PHMM_OK;
