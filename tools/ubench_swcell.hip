@@ -59,6 +59,33 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint8_t *planes, size_t 
                       [wopen] "v"(wo), [wm] "v"(wm), [wmm] "v"(wmm)
                     : "vcc");
             }
+            else if (FORM == 6) {
+                asm volatile(
+                    "v_cmp_eq_u32 vcc, %[b1], %[b2]\n\t"
+                    "v_add_u32 %[exth], %[e], %[wext]\n\t"
+                    "v_add_u32 %[openh], %[hl], %[wopen]\n\t"
+                    "v_cndmask_b32 %[sc], %[wmm], %[wm], vcc\n\t"
+                    "v_sub_co_u32 %[d], vcc, %[exth], %[openh]\n\t"
+                    "v_add_u32 %[m11], %[hd], %[sc]\n\t"
+                    "v_add_u32 %[extv], %[f11], %[wext]\n\t"
+                    "v_cndmask_b32 %[e11], %[exth], %[openh], vcc\n\t"
+                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                    "v_add_u32 %[openv], %[hp], %[wopen]\n\t"
+                    "v_sub_co_u32 %[d], vcc, %[extv], %[openv]\n\t"
+                    "v_cndmask_b32 %[f11], %[extv], %[openv], vcc\n\t"
+                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                    "v_sub_co_u32 %[d], vcc, %[m11], %[e11]\n\t"
+                    "v_cndmask_b32 %[h1], %[m11], %[e11], vcc\n\t"
+                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                    "v_sub_co_u32 %[d], vcc, %[h1], %[f11]\n\t"
+                    "v_cndmask_b32 %[h11], %[h1], %[f11], vcc\n\t"
+                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
+                    : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "+v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth), [openh] "=&v"(t_openh),
+                      [sc] "=&v"(t_sc), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv), [h1] "=&v"(t_h1), [d] "=&v"(t_d)
+                    : [b1] "v"(base1), [b2] "v"(b2[kk]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [hp] "v"(Hp[kk]), [wext] "v"(we),
+                      [wopen] "v"(wo), [wm] "v"(wm), [wmm] "v"(wmm)
+                    : "vcc");
+            }
             else {
                 // the same cell; each borrow mask goes to an SGPR pair right after the select that consumes it
 #define CELL(M1, M2, M3, M4, TAIL)                                                                                                         \
@@ -164,6 +191,7 @@ int main()
     const size_t plane_bytes = (size_t)4096 * 400 * K * 32 + 4096;
     CHECK(hipMalloc(&out, 256 * 4 * 256 * sizeof(uint32_t))); CHECK(hipMalloc(&planes, plane_bytes)); CHECK(hipMalloc(&clk, 16));
     run<0>("shipped cell (4 v_addc_co_u32)", out, planes, plane_bytes, clk);
+    run<6>("shipped cell without its three s_nop (timing)", out, planes, plane_bytes, clk);
     run<3>("bits dropped (lower bound)", out, planes, plane_bytes, clk);
     run<1>("borrow masks to SGPR pairs (4 s_mov_b64)", out, planes, plane_bytes, clk);
     run<2>("... + 2 s_store_dwordx4 per cell", out, planes, plane_bytes, clk);
