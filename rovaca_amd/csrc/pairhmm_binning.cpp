@@ -30,6 +30,43 @@ bool queue_per_class_for(uint64_t n_pairs) { return n_pairs > kQueuePerClassMinP
 namespace phmm_detail
 {
 
+// Small launches ride along.  A launch of a few hundred pairs costs a lone wave's whole sweep (50-90 us) whatever its size, and a
+// batch of mixed read lengths has one launch per rows-per-lane value: a stage of seven regions whose reads were trimmed to anything
+// between 50 and 151 bases is seven launches, six of them nearly empty (measured through the adapter: regions of mixed shape ran at a
+// third of the rate of uniform ones).  So a single-pass bin with fewer than kMergeBelowPairs pairs (two rounds of
+// the chip's wave slots) is handed to the next bin up: its
+// pairs run with that bin's rows per lane -- the kernels pad a shorter read with boundary rows in front, as they do inside a class --
+// at the price of idle rows that a launch this small could not have filled the chip with anyway.  A bin that is not small is never
+// given more rows per lane, and batches big enough for per-class rescue queues are left alone.
+// Threshold, measured (MI355X): through the adapter on regions of mixed shape, 30 synchronous workers 42 -> 70 / 87 / 87 / 90 k regions/s for
+// 1 024 / 2 048 / 4 096 / 8 192 (no gain beyond), 30 x 4 in flight 94 -> 99 / 113 / 118 / 126; resident sweeps of 30 000 pairs with reads of
+// 50-250 bases 2 250 -> 2 630 (2 048) -> 3 010 GCUPS (8 192), of 50 000 pairs 3 230 -> 3 270 -> 3 590.
+constexpr uint32_t kMergeBelowPairs = 8192;
+static void merge_small_bins(std::vector<Bin> &bins, bool queue_per_class)
+{
+    if (queue_per_class || bins.size() < 2 || phmm_hook("PHMM_NO_BIN_MERGE")) return;
+    uint32_t below = kMergeBelowPairs;
+    if (const char *f = phmm_hook("PHMM_MERGE_BELOW_PAIRS")) below = (uint32_t)std::max(0, atoi(f));  // tuning
+    std::vector<Bin> out;
+    out.reserve(bins.size());
+    bool open = false;  // out.back() is a single-pass bin that the next single-pass bin may absorb
+    for (const Bin &b : bins) {
+        if (b.rows_per_lane > 0 && open && out.back().count < below && out.back().first + out.back().count == b.first &&
+            out.back().queue == b.queue) {
+            Bin &a = out.back();  // a's pairs come first in `order`; they take b's (larger) rows per lane
+            a.rows_per_lane = std::max(a.rows_per_lane, b.rows_per_lane);
+            a.count += b.count;
+            a.lds_words_per_group = std::max(a.lds_words_per_group, b.lds_words_per_group);
+            a.max_hap_len = std::max(a.max_hap_len, b.max_hap_len);
+            a.max_read_len = std::max(a.max_read_len, b.max_read_len);
+            continue;
+        }
+        out.push_back(b);
+        open = b.rows_per_lane > 0;
+    }
+    bins.swap(out);
+}
+
 int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_bias, uint32_t hap_bias, uint32_t *pr, uint32_t *ph,
               uint32_t *order, BinScratch &scratch, std::vector<Bin> &bins, uint64_t *cells_out)
 {
@@ -188,6 +225,7 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
             i = j;
         }
     }
+    merge_small_bins(bins, queue_per_class);
     *cells_out = cells;
     return PHMM_OK;
 }
@@ -262,6 +300,7 @@ int bin_regions(const phmm_region *regions, uint32_t n_regions, const uint32_t *
             cursor[k] += rg.n_haps;
         }
     }
+    merge_small_bins(bins, queue_per_class);
     *cells_out = cells;
     *n_pairs_out = n_pairs;
     return PHMM_OK;

@@ -152,6 +152,29 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
         cells += (uint64_t)l1 * l2;
         worst_elems += (uint64_t)l1 + l2 + 2;
     }
+    // Small batches (everything one alignment per wave): a launch per columns-per-lane value costs a lone wave's sweep each, one after
+    // the other on the stream, and a region whose reads were trimmed to different lengths has two or three of them.  A class rides along
+    // with the next one up -- its alignments simply leave the upper lanes idle -- as long as that at most doubles its columns per lane.
+    if (n <= kWideMaxPairs && !getenv("SWHIP_NO_CLASS_MERGE")) {
+        bool present[128] = {false};
+        for (uint64_t key : keys) present[(key >> 48) & 127] = true;
+        uint8_t to[128];
+        for (int i = 0; i < 128; ++i) to[i] = (uint8_t)i;
+        int group_min = 0, members[128], n_members = 0;
+        for (int cls = 65; cls < 128; ++cls) {  // 64 + k: the one-alignment-per-wave classes, ascending
+            if (!present[cls]) continue;
+            const int k = cls - 64;
+            if (n_members && k <= 2 * group_min) {
+                for (int i = 0; i < n_members; ++i) to[members[i]] = (uint8_t)cls;  // the group now runs with this class's columns per lane
+            }
+            else {
+                n_members = 0;
+                group_min = k;
+            }
+            members[n_members++] = cls;
+        }
+        for (uint64_t &key : keys) key = (key & 0x0000FFFFFFFFFFFFull) | ((uint64_t)to[(key >> 48) & 127] << 48);
+    }
     std::sort(keys.begin(), keys.end());
     const uint64_t m = keys.size();
     if (stats) stats->cells = cells;

@@ -46,6 +46,7 @@ def test_device_line_has_roofline_and_cpu_baseline():
     assert "error" not in ad, ad
     assert ad["bit_identical_to_resident_path"] is True and ad["value"] > 0 and ad["synchronous_seam"]["value"] > 0
     assert ad["workers"] >= 1 and ad["regions_per_submission"] >= 1.0 and ad["regions"] == ad["workers"] * 2000
+    assert ad["mixed_shapes"]["value"] > 0 and ad["mixed_shapes"]["synchronous_seam"]["value"] > 0  # regions that are not all alike
 
 
 def test_committed_pmc_counters_belong_to_the_committed_kernels():

@@ -63,14 +63,20 @@ def test_config2_sample_150x300(engine):
     _check_against_oracle(engine, synth.make_config("c2", scale=0.02))
 
 
+@pytest.mark.parametrize("merge", [False, True])
 @pytest.mark.parametrize("lanes", [16, 64])
-def test_config3_sample_mixed_lengths(engine, lanes, monkeypatch):
+def test_config3_sample_mixed_lengths(engine, lanes, merge, monkeypatch):
+    if not merge:
+        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # one launch per rows-per-lane value (small ones otherwise ride along)
     monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
     _check_against_oracle(engine, synth.make_config("c3", scale=0.02))
 
 
+@pytest.mark.parametrize("merge", [False, True])
 @pytest.mark.parametrize("lanes", [16, 64])
-def test_every_rows_per_lane_bin(engine, lanes, monkeypatch):
+def test_every_rows_per_lane_bin(engine, lanes, merge, monkeypatch):
+    if not merge:
+        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # one launch per rows-per-lane value (small ones otherwise ride along)
     # read lengths 1..256 hit every K = ceil(R/16) instantiation, including exact multiples of 16, in both shapes of the
     # single-pass kernel: four pairs per wave (16 lanes each) and one pair per wave (64 lanes, K = ceil(R/64))
     monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
@@ -94,8 +100,11 @@ def test_every_rows_per_lane_bin(engine, lanes, monkeypatch):
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
+@pytest.mark.parametrize("merge", [False, True])
 @pytest.mark.parametrize("lanes", [16, 64])
-def test_general_gap_parameters(engine, lanes, monkeypatch):
+def test_general_gap_parameters(engine, lanes, merge, monkeypatch):
+    if not merge:
+        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # one launch per rows-per-lane value (small ones otherwise ride along)
     # per-base ins / del / gcp all different: exercises the non-uniform-gcp kernel variant
     monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
     rng = np.random.default_rng(6)
@@ -387,8 +396,11 @@ def test_band_kernel_pair_joining_late_beside_a_stripe_that_began_mid_row(engine
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
+@pytest.mark.parametrize("merge", [False, True])
 @pytest.mark.parametrize("lanes", [16, 64])
-def test_uniform_gap_open_kernel_is_the_general_one(engine, lanes, monkeypatch):
+def test_uniform_gap_open_kernel_is_the_general_one(engine, lanes, merge, monkeypatch):
+    if not merge:
+        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # one launch per rows-per-lane value (small ones otherwise ride along)
     # batches with one gap-open quality throughout (PCR-free data, the synthetic configs) take the variant that shares p_mm / p_mx
     # and reuses M * p_mx for the Y of the next step: same bits as the Rovaca-case kernel (PHMM_NO_UNIFORM_GOP=1) and as the oracle,
     # for every rows-per-lane value, with padding rows, N and foreign symbols; a batch with ONE deviating base must not take it

@@ -110,9 +110,14 @@ def test_backtrack_memory_is_reused_across_launches(aligner, monkeypatch):
     assert st.n_launches > 3
 
 
+@pytest.mark.parametrize("merge", [False, True])
 @pytest.mark.parametrize("lanes,lds_flags", [(16, False), (64, False), (64, True)])
-def test_every_geometry_and_long_sequences(aligner, lanes, lds_flags, monkeypatch):
-    # both shapes; with one alignment per wave the backtrack flags live in LDS for small batches, in global memory otherwise
+def test_every_geometry_and_long_sequences(aligner, lanes, lds_flags, merge, monkeypatch):
+    # both shapes; with one alignment per wave the backtrack flags live in LDS for small batches, in global memory otherwise.  In a
+    # small batch a columns-per-lane class rides along with the next one up (its alignments leave the upper lanes idle); without the
+    # merge every instantiation gets its own launch
+    if not merge:
+        monkeypatch.setenv("SWHIP_NO_CLASS_MERGE", "1")
     monkeypatch.setenv("SWHIP_FORCE_LANES", str(lanes))
     if not lds_flags:
         monkeypatch.setenv("SWHIP_NO_LDS_FLAGS", "1")

@@ -27,14 +27,37 @@ def test_pair_binning_orders_by_class_then_haplotype_length_then_index():
         R, H = b.read_len[b.pair_read[order]].astype(int), b.hap_len[b.pair_hap[order]].astype(int)
         key = [(_class(r, h), -h, int(p)) for r, h, p in zip(R, H, order)]
         assert key == sorted(key)
-        # launches: contiguous, cover the order, one per single-pass class, striped classes grouped in four size ranges
+        # launches: contiguous, cover the order; striped classes grouped in four size ranges; a single-pass launch runs with the rows
+        # per lane of its highest class, and classes share a launch only where everything below the highest is a small remainder
+        # (fewer than 8 192 pairs: they ride along instead of paying a launch of their own)
         at = 0
         for rows, first, count in bins:
             assert first == at and count > 0
-            ids = {_bin_id(_class(r, h)) for r, h in zip(R[first:first + count], H[first:first + count])}
-            assert len(ids) == 1 and (rows == next(iter(ids)) if rows else next(iter(ids)) >= 17)
+            ids = [_bin_id(_class(r, h)) for r, h in zip(R[first:first + count], H[first:first + count])]
+            if rows:
+                assert max(ids) == rows and ids == sorted(ids) and sum(i < rows for i in ids) < 8192
+            else:
+                assert len(set(ids)) == 1 and ids[0] >= 17
             at += count
         assert at == b.n_pairs
+
+
+def test_small_launches_ride_along_with_the_next_class(monkeypatch):
+    # 3 000 pairs of 151-base reads (10 rows per lane) and a sprinkling of trimmed ones: one launch instead of one per class; without the
+    # merge (PHMM_NO_BIN_MERGE, the A/B hook) every class has its own.  A class that is not small keeps its rows per lane.
+    reads = [(np.full(n, 65, np.uint8),) * 5 for n in [151] * 60 + [40, 70, 100, 120, 135]]
+    haps = [np.full(300, 65, np.uint8)] * 50
+    b = Batch.from_lists(reads, haps)
+    _, bins = capi.plan_bins(b, cross=True)
+    assert [(r, c) for r, _, c in bins] == [(10, 65 * 50)]
+    monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")
+    _, plain = capi.plan_bins(b, cross=True)
+    assert [(r, c) for r, _, c in plain] == [(3, 50), (5, 50), (7, 50), (8, 50), (9, 50), (10, 3000)]
+    monkeypatch.delenv("PHMM_NO_BIN_MERGE")
+    reads = [(np.full(n, 65, np.uint8),) * 5 for n in [100] * 170 + [151] * 170 + [250]]
+    b = Batch.from_lists(reads, haps)
+    _, bins = capi.plan_bins(b, cross=True)
+    assert [(r, c) for r, _, c in bins] == [(7, 8500), (10, 8500), (16, 50)]  # 8 500 pairs at 7 rows are not made to run at 10
 
 
 def test_pair_binning_sparse_lengths_take_the_comparison_sort_and_agree():
@@ -69,9 +92,9 @@ def test_region_binning_places_every_read_and_matches_the_pair_plan():
         hmax = int(b.hap_len[h0:h0 + nh].max())
         for r in range(r0, r0 + nr):
             k = _bin_id(_class(int(b.read_len[r]), hmax))
-            rows, first, count = next(x for x in bins if (x[0] == k if k < 17 else x[0] == 0 and True))
-            if k < 17:
-                assert first <= slot[r] and slot[r] + nh <= first + count
+            if k < 17:  # inside one single-pass launch whose rows per lane are enough for this read
+                rows, first, count = next(x for x in bins if x[1] <= slot[r] < x[1] + x[2])
+                assert rows >= k and slot[r] + nh <= first + count
             assert not taken[slot[r]:slot[r] + nh].any()
             taken[slot[r]:slot[r] + nh] = True
     assert taken.all()

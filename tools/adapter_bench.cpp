@@ -265,19 +265,25 @@ int main(int argc, char **argv)
     std::vector<uint8_t> rb, rq, mq, hb;
     std::vector<uint32_t> roff, rlen, hoff, hlen, region_read{0}, region_hap{0};
     const char acgt[] = "ACGT";
-    for (int i = 0; i < 16; ++i) {
+    // ADAPTER_BENCH_MIXED=1: 64 templates of mixed shape instead (8-135 reads of 151 bases, a fifth of them trimmed to 50-150, against
+    // 2-21 haplotypes of 160-500 bases) -- what the stages and the length bins make of regions that are not all alike
+    const bool mixed = getenv("ADAPTER_BENCH_MIXED") != nullptr;
+    const int n_templates = mixed ? 64 : 16;
+    for (int i = 0; i < n_templates; ++i) {
         std::mt19937 rng(1000 + i);
-        const int R = 150, H = 300;
+        const int H = mixed ? 160 + (int)(rng() % 341) : 300;
+        const int n_reads_i = mixed ? 8 + (int)(rng() % 128) : n_reads, n_haps_i = mixed ? 2 + (int)(rng() % 20) : n_haps;
         std::vector<uint8_t> base(H);
         for (auto &c : base) c = acgt[rng() & 3];
-        for (int h = 0; h < n_haps; ++h) {
+        for (int h = 0; h < n_haps_i; ++h) {
             std::vector<uint8_t> x = base;
             if (h) for (int k = 0; k < 3; ++k) x[rng() % H] = acgt[rng() & 3];
             hoff.push_back((uint32_t)hb.size());
             hlen.push_back(H);
             hb.insert(hb.end(), x.begin(), x.end());
         }
-        for (int r = 0; r < n_reads; ++r) {
+        for (int r = 0; r < n_reads_i; ++r) {
+            const int R = !mixed ? 150 : rng() % 5 ? 151 : 50 + (int)(rng() % 101);
             const int st = rng() % (H - R + 1);
             roff.push_back((uint32_t)rb.size());
             rlen.push_back(R);
@@ -302,7 +308,7 @@ int main(int argc, char **argv)
     a.hap_len = hlen.data();
     a.region_read = region_read.data();
     a.region_hap = region_hap.data();
-    a.n_regions = 16;
+    a.n_regions = n_templates;
     a.threads = threads;
     a.regions_per_thread = per_thread;
     a.depth = depth;
