@@ -87,6 +87,7 @@ struct swhip_context
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_done = nullptr;  // SWHIP_BLOCKING_SYNC=1: the call's one wait sleeps in the driver instead of polling
     DevBytes blob, bt, scratch, cigars;
     HostBytes stage, back, back_cigars;
 };
@@ -284,15 +285,25 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
         a.order = reinterpret_cast<const uint32_t *>(base + o_order) + l.first;
         a.n_pairs = l.count;
         a.lds_stride = (l.max_len1 + 15u) & ~15u;
-        // small one-alignment-per-wave launches keep their flags in LDS: the traceback then waits ~100 cycles per step, not ~700
+        // SWHIP_LDS_FLAGS=1: small one-alignment-per-wave launches keep their flags in LDS (the traceback then waits ~100 cycles per
+        // fetch, not ~700).  Off by default since the lanes of an alignment walk the traceback together (a fetch per 64 diagonal
+        // moves): a lone region-sized call gains 3 % from it (136 against 140 us), but ~55 KB of LDS per alignment lets a CU hold two,
+        // and with several calls in flight -- the adapter's case -- they queue for it (30 workers x 4 regions in flight: 118 000
+        // regions/s with, 126 000 without).
         const uint64_t bt_bytes = swhip::bt_words(l.max_len1, l.lanes, l.k) * 4;
-        const bool in_lds = l.lanes == 64 && l.count <= kLdsFlagsMaxPairs && a.lds_stride + bt_bytes <= 150u * 1024u && !getenv("SWHIP_NO_LDS_FLAGS");
+        const bool in_lds = l.lanes == 64 && l.count <= kLdsFlagsMaxPairs && a.lds_stride + bt_bytes <= 150u * 1024u && getenv("SWHIP_LDS_FLAGS");
         a.bt_in_lds = in_lds ? 1u : 0u;
         a.lds_bt_bytes = in_lds ? (uint32_t)bt_bytes : 0u;
         HIP_TRY(swhip::launch_sw(l.k, l.lanes, a, st));
     }
     if (stats) HIP_TRY(hipEventRecord(c->ev1, st));
-    HIP_TRY(hipStreamSynchronize(st));  // the one wait of the call
+    if (c->ev_done) {  // the one wait of the call
+        HIP_TRY(hipEventRecord(c->ev_done, st));
+        HIP_TRY(hipEventSynchronize(c->ev_done));
+    }
+    else {
+        HIP_TRY(hipStreamSynchronize(st));
+    }
 
     // every alignment took its elements from the cursor in one piece, so the highest end is the number used
     const swhip_alignment *dev_res = static_cast<const swhip_alignment *>(c->back.p);
@@ -362,6 +373,7 @@ int swhip_create(int device_id, void *stream, swhip_context **out)
     }
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess && getenv("SWHIP_BLOCKING_SYNC")) e = hipEventCreateWithFlags(&c->ev_done, hipEventBlockingSync | hipEventDisableTiming);
     if (e != hipSuccess) {
         swhip_destroy(c);
         return fail(SWHIP_E_HIP, "swhip_create: %s", hipGetErrorString(e));
@@ -377,6 +389,7 @@ void swhip_destroy(swhip_context *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

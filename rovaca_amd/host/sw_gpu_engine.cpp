@@ -21,6 +21,7 @@
 #include "../../include/smithwaterman_hip.h"
 
 #include <algorithm>
+#include <chrono>
 
 namespace
 {
@@ -31,8 +32,11 @@ namespace
 std::atomic<int> g_sw_device{-1};
 std::atomic<uint32_t> g_sw_next_device{0};
 
+thread_local int t_sw_device = -1;  // a dispatcher thread's own device (set before its context exists)
+
 int pick_device()
 {
+    if (t_sw_device >= 0) return t_sw_device;
     const int fixed = g_sw_device.load();
     if (fixed >= 0) return fixed;
     const int n = swhip_device_count();
@@ -65,6 +69,22 @@ namespace
 using rovaca::SwAlignment;
 using rovaca::SwJob;
 
+// Where the realignment seam's host time goes (always on, as gpu_pairhmm_profile): nanoseconds summed over threads, plus two counters
+enum SwProfileSlot {
+    kSwWorkerBlocked,   // worker: from handing the request over until it is woken
+    kSwWorkerUnpack,    // worker: building the per-alignment vectors the seam returns
+    kSwQueueWait,       // requests: from submit until a dispatcher takes them (summed over requests)
+    kSwDispGather,      // dispatcher: concatenating the requests' sequences into one batch
+    kSwDispDeviceCall,  // dispatcher: swhip_align (classify, one copy, launches, the wait)
+    kSwDeviceKernels,   // ... of which device time of the launches (HIP events)
+    kSwDispScatter,     // dispatcher: copying each request's slice out and waking it
+    kSwDispIdle,        // dispatcher: nothing queued
+    kSwRequests, kSwDeviceCalls,  // counters
+    kSwProfSlots
+};
+std::atomic<uint64_t> g_sw_prof[kSwProfSlots];
+static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // reusable host buffers of one device call (per calling thread: a dispatcher, or a worker on the unbatched path)
 struct CallBuffers
 {
@@ -77,6 +97,7 @@ struct CallBuffers
 // one device call for `n` jobs on the calling thread's context; results in buf.res / buf.cigars (cigar_off indexes buf.cigars)
 bool align_raw(const SwJob *jobs, size_t n, const sw_parameters &para, CallBuffers &buf)
 {
+    const uint64_t t0 = now_ns();
     buf.refs.clear();
     buf.seqs.clear();
     buf.roff.resize(n);
@@ -110,7 +131,11 @@ bool align_raw(const SwJob *jobs, size_t n, const sw_parameters &para, CallBuffe
     buf.res.resize(n);
     if (buf.cigars.size() < cap) buf.cigars.resize(cap);
     uint64_t used = 0;
-    if (swhip_align(t_ctx.get(), &prm, &b, buf.res.data(), buf.cigars.data(), cap, &used, nullptr) != SWHIP_OK) {
+    swhip_stats stats{};
+    g_sw_prof[kSwDispGather].fetch_add(now_ns() - t0, std::memory_order_relaxed);
+    const int rc = swhip_align(t_ctx.get(), &prm, &b, buf.res.data(), buf.cigars.data(), cap, &used, &stats);
+    g_sw_prof[kSwDeviceKernels].fetch_add((uint64_t)(stats.kernel_ms * 1e6), std::memory_order_relaxed);
+    if (rc != SWHIP_OK) {
         fprintf(stderr, "[rovaca_amd] smith-waterman: %s\n", swhip_last_error());
         return false;
     }
@@ -160,26 +185,35 @@ struct Request
     std::vector<uint32_t> cigars;
     bool ok = true;
     std::atomic<uint32_t> done{0};     // futex word
+    uint64_t t_submit = 0;             // profile: when it was queued
 };
 
 class SwBatcher
 {
 public:
-    SwBatcher() : worker_([this] { run(); }) {}
+    // one queue per device, `n_threads` dispatchers behind it: whichever is free takes everything that is waiting, so a request never
+    // sits behind a busy dispatcher while another one idles (round 3; before, every dispatcher had a queue of its own)
+    SwBatcher(int device, int n_threads)
+    {
+        for (int i = 0; i < n_threads; ++i) threads_.emplace_back([this, device] { run(device); });
+    }
     // the request (and what it points at) must stay alive until wait() has returned
     void submit(Request &rq)
     {
         bool wake;
+        rq.t_submit = now_ns();
         {
             std::lock_guard<std::mutex> lk(mu_);
             queue_.push_back(&rq);
-            wake = sleeping_;
+            wake = sleeping_ > 0;
         }
         if (wake) cv_.notify_one();
     }
     static bool wait(Request &rq)
     {
+        const uint64_t t0 = now_ns();
         while (rq.done.load(std::memory_order_acquire) == 0) futex_call(&rq.done, FUTEX_WAIT_PRIVATE, 0);
+        g_sw_prof[kSwWorkerBlocked].fetch_add(now_ns() - t0, std::memory_order_relaxed);
         return rq.ok;
     }
     bool submit_and_wait(Request &rq)
@@ -194,8 +228,9 @@ private:
     {
         return a.match == b.match && a.mismatch == b.mismatch && a.gap_open == b.gap_open && a.gap_extend == b.gap_extend;
     }
-    void run()
+    void run(int device)
     {
+        t_sw_device = device;
         // named like the reference's own threads (haplotypecaller_engine.cpp:120) so that perf / top -H attribute the time
         pthread_setname_np(pthread_self(), "sw-gpu-disp");
         std::vector<Request *> taken, group;
@@ -203,12 +238,20 @@ private:
         CallBuffers buf;
         for (;;) {
             {
+                const uint64_t t_idle = now_ns();
                 std::unique_lock<std::mutex> lk(mu_);
-                sleeping_ = true;
+                ++sleeping_;
                 cv_.wait(lk, [&] { return !queue_.empty(); });
-                sleeping_ = false;
+                --sleeping_;
                 taken.assign(queue_.begin(), queue_.end());
                 queue_.clear();
+                lk.unlock();
+                const uint64_t t_taken = now_ns();
+                g_sw_prof[kSwDispIdle].fetch_add(t_taken - t_idle, std::memory_order_relaxed);
+                uint64_t waited = 0;
+                for (Request *r : taken) waited += t_taken - r->t_submit;
+                g_sw_prof[kSwQueueWait].fetch_add(waited, std::memory_order_relaxed);
+                g_sw_prof[kSwRequests].fetch_add(taken.size(), std::memory_order_relaxed);
             }
             while (!taken.empty()) {
                 group.clear();
@@ -222,9 +265,13 @@ private:
                         ++it;
                     }
                 }
+                const uint64_t t_g = now_ns();
                 jobs.clear();
                 for (Request *r : group) jobs.insert(jobs.end(), r->jobs, r->jobs + r->n);
                 const bool ok = align_raw(jobs.data(), jobs.size(), para, buf);
+                const uint64_t t_called = now_ns();
+                g_sw_prof[kSwDispDeviceCall].fetch_add(t_called - t_g, std::memory_order_relaxed);  // (align_raw reports its gather share itself)
+                g_sw_prof[kSwDeviceCalls].fetch_add(1, std::memory_order_relaxed);
                 requests += group.size();
                 submissions += 1;
                 size_t at = 0;
@@ -250,14 +297,15 @@ private:
                     r->done.store(1);
                     futex_call(word, FUTEX_WAKE_PRIVATE, INT32_MAX);
                 }
+                g_sw_prof[kSwDispScatter].fetch_add(now_ns() - t_called, std::memory_order_relaxed);
             }
         }
     }
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<Request *> queue_;
-    bool sleeping_ = false;  // guarded by mu_
-    std::thread worker_;
+    int sleeping_ = 0;  // dispatchers waiting for work; guarded by mu_
+    std::vector<std::thread> threads_;
 };
 
 std::vector<SwBatcher *> g_sw_batchers;  // never destroyed: their threads would call into HIP during static teardown
@@ -276,9 +324,10 @@ void start_batchers()
     // 13.5 and 128 x 4 (the cores are the limit there) 161 / 113 / 109.
     int n = nd ? atoi(nd) : 2;
     n = n < 1 ? 1 : n > 16 ? 16 : n;
-    // with round-robin devices every device gets its dispatchers (a dispatcher's context is created on its own thread)
-    const int devices = g_sw_device.load() < 0 ? std::max(1, swhip_device_count()) : 1;
-    for (int i = 0; i < n * devices; ++i) g_sw_batchers.push_back(new SwBatcher());
+    // with round-robin devices every device gets its queue and dispatchers (a dispatcher's context is created on its own thread)
+    const int fixed = g_sw_device.load();
+    const int devices = fixed < 0 ? std::max(1, swhip_device_count()) : 1;
+    for (int d = 0; d < devices; ++d) g_sw_batchers.push_back(new SwBatcher(fixed < 0 ? d : fixed, n));
 }
 
 // a request as the worker prepares it: result slots sized, CIGAR buffer with room for the usual handful of elements per alignment
@@ -305,7 +354,9 @@ bool sw_hip_align_batch(const SwJob *jobs, size_t n, const sw_parameters &para, 
     Request rq;
     prepare(rq, jobs, n, para);
     if (!g_sw_batchers[g_sw_next.fetch_add(1) % g_sw_batchers.size()]->submit_and_wait(rq)) return false;
+    const uint64_t t_u = now_ns();
     unpack(rq.res.data(), rq.cigars.data(), n, out.data());
+    g_sw_prof[kSwWorkerUnpack].fetch_add(now_ns() - t_u, std::memory_order_relaxed);
     return true;
 }
 
@@ -364,8 +415,10 @@ bool sw_hip_align_batch_finish(SwTicket &&ticket, std::vector<SwAlignment> &out)
         st.ok = SwBatcher::wait(st.rq);
         st.batcher = nullptr;
         if (st.ok) {
+            const uint64_t t_u = now_ns();
             out.assign(st.rq.n, SwAlignment{});
             unpack(st.rq.res.data(), st.rq.cigars.data(), st.rq.n, out.data());
+            g_sw_prof[kSwWorkerUnpack].fetch_add(now_ns() - t_u, std::memory_order_relaxed);
         }
         return st.ok;
     }
@@ -465,6 +518,20 @@ int sw_hip_align_many(p_lib_sw_avx *handles, size_t n)
 }
 
 void sw_hip_set_device(int device_id) { g_sw_device.store(device_id); }
+
+int sw_hip_profile(double *values, const char **names, int cap)
+{
+    static const char *const kNames[kSwProfSlots] = {"sw worker: blocked until its alignments are back", "sw worker: building the per-alignment results",
+                                                     "sw requests: queued until a dispatcher took them", "sw dispatcher: gathering the requests' sequences",
+                                                     "sw dispatcher: gather + swhip_align (copy, launches, wait)", "sw device: time of the launches (HIP events)",
+                                                     "sw dispatcher: handing slices back, waking", "sw dispatcher: idle (nothing queued)",
+                                                     "sw requests (count)", "sw device calls (count)"};
+    for (int i = 0; i < kSwProfSlots && i < cap; ++i) {
+        if (values) values[i] = i >= kSwRequests ? (double)g_sw_prof[i].load() : (double)g_sw_prof[i].load() * 1e-9;
+        if (names) names[i] = kNames[i];
+    }
+    return kSwProfSlots;
+}
 
 int sw_hip_install(p_lib_sw_avx p)
 {

@@ -45,6 +45,10 @@ int sw_hip_install(p_lib_sw_avx p);
 // first alignment.
 void sw_hip_set_device(int device_id);
 
+// Where the batched realignment seam's host time went so far (always on; seconds summed over threads, the last two entries are counts
+// of requests and of device calls): fills up to `cap` entries of `values` / `names` (either may be null), returns the number of entries.
+int sw_hip_profile(double *values, const char **names, int cap);
+
 #ifdef __cplusplus
 }
 

@@ -119,8 +119,8 @@ def test_every_geometry_and_long_sequences(aligner, lanes, lds_flags, merge, mon
     if not merge:
         monkeypatch.setenv("SWHIP_NO_CLASS_MERGE", "1")
     monkeypatch.setenv("SWHIP_FORCE_LANES", str(lanes))
-    if not lds_flags:
-        monkeypatch.setenv("SWHIP_NO_LDS_FLAGS", "1")
+    if lds_flags:
+        monkeypatch.setenv("SWHIP_LDS_FLAGS", "1")
     # seq2 lengths across every columns-per-lane instantiation of both shapes (16 and 64 lanes per alignment)
     rng = np.random.default_rng(9)
     acgt = np.frombuffer(b"ACGT", np.uint8)
@@ -148,7 +148,6 @@ def test_gap_rich_paths_leave_the_diagonal_often(aligner, lanes, monkeypatch):
     # (sw_kernels.hip): paths with many short and long gaps, runs that open and extend in both directions, unrelated sequences
     # and low-complexity repeats make it re-fetch at every kind of move; parameters with cheap gaps make the gaps frequent
     monkeypatch.setenv("SWHIP_FORCE_LANES", str(lanes))
-    monkeypatch.setenv("SWHIP_NO_LDS_FLAGS", "1")
     rng = np.random.default_rng(31 + lanes)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     refs, seqs, pairs = [], [], []

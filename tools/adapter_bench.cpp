@@ -334,6 +334,17 @@ int main(int argc, char **argv)
         gpu_pairhmm_profile(dummy, names, 16);
         for (int i = 0; i < r.n_phases; ++i)
             fprintf(stderr, "  %-58s %9.3f s  %8.2f us/region\n", names[i], r.phase_seconds[i], r.phase_seconds[i] / (double)r.regions * 1e6);
+        if (with_sw) {  // (since process start: the timed run and nothing else in this program)
+            const char *sw_names[16] = {nullptr};
+            double sw_values[16];
+            const int n_sw = sw_hip_profile(sw_values, sw_names, 16);
+            for (int i = 0; i < n_sw; ++i) {
+                if (i >= n_sw - 2)
+                    fprintf(stderr, "  %-58s %9.0f    %8.2f per region\n", sw_names[i], sw_values[i], sw_values[i] / (double)r.regions);
+                else
+                    fprintf(stderr, "  %-58s %9.3f s  %8.2f us/region\n", sw_names[i], sw_values[i], sw_values[i] / (double)r.regions * 1e6);
+            }
+        }
     }
     return 0;
 }
