@@ -69,6 +69,11 @@ int phmm_create(int device_id, void *stream, phmm_context **out)
 {
     if (!out || device_id < 0) return fail(PHMM_E_INVALID, "phmm_create: bad arguments");
     *out = nullptr;
+    // A context drives up to six streams (sweep, three side streams, upload, download) and a process usually holds several contexts;
+    // the HIP runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, and streams that share one take turns.
+    // Ask for 16 unless the user chose -- effective only when this is the process's first HIP call (the adapter's
+    // init_pairhmm_ptr_gpu and bench.py set it earlier for that reason).
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(PHMM_E_NO_DEVICE, "phmm_create: no HIP device visible (this engine has no CPU fallback)");
@@ -339,7 +344,8 @@ int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const U
 
     // ---- upload ----
     if (opt.setup_stream && opt.setup_stream != st) {
-        // The chunked call: the set-up launch goes on the sweep stream and must see the copy.  A device-side wait there
+        // The chunked call's synchronous form (PHMM_CHUNK_SYNC_UPLOAD; the default until the process asked for 16 hardware queues): the
+        // set-up launch goes on the sweep stream and must see the copy.  A device-side wait there
         // (hipStreamWaitEvent) cost ~50 us of idle queue at every chunk boundary, and an event behind an asynchronous copy on the
         // upload stream does not fire before the sweep that is running has drained (its marker sits in a compute queue the busy
         // chip does not get round to: measured, hipEventSynchronize returned 1.7 ms late).  A synchronous copy waits on the DMA

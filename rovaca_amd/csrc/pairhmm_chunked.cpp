@@ -327,6 +327,12 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         // has handed out its last workgroup -- small kernels of another queue are starved by a grid that fills the chip -- and the
         // sweep behind it would wait with it: 90-110 us of a drained chip at every chunk boundary (rocprofv3 time line, round 3).
         opt.setup_stream = c->stream;
+        // Since the process asks for 16 hardware queues (phmm_create; the runtime's default of 4 made the upload stream share a queue
+        // with the sweeps, which is what the two findings above were): copy and set-up launch both on the upload stream, the sweep behind
+        // an event, and the packing thread never waits for a copy.  8.62-8.68 ms per call on config 2 against 8.74-8.75 with the
+        // synchronous copy + set-up on the sweep stream (PHMM_CHUNK_SYNC_UPLOAD=1 keeps that form; with 4 queues the two are equal).
+        const bool async_upload = phmm_hook("PHMM_CHUNK_SYNC_UPLOAD") == nullptr && up != c->stream;
+        if (async_upload) opt.setup_stream = nullptr;
         if (k == 0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
         PhaseClock chunk_clock;
         struct PhaseScope
@@ -343,6 +349,10 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         HIP_TRY(rb->out_stage.ensure(count_at * sizeof(float) + 256 + n * sizeof(double)));
         rb->out32_host = direct ? static_cast<float *>(rb->out_stage.p) : nullptr;
         rb->out64_host = direct ? reinterpret_cast<double *>(static_cast<uint8_t *>(rb->out_stage.p) + count_at * sizeof(float) + 256) : nullptr;
+        if (async_upload) {
+            HIP_TRY(hipEventRecord(c->chunk_up[slot], up));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->chunk_up[slot], 0));
+        }
         rc = impl::phmm_sweep(c, rb);
         if (rc != PHMM_OK) return rc;
         PHASE(4);
