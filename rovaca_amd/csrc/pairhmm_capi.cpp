@@ -162,6 +162,19 @@ void phmm_destroy(phmm_context *c)
         (void)hipStreamSynchronize(c->down);
         (void)hipStreamDestroy(c->down);
     }
+    if (c->lane2.stream) {
+        (void)hipStreamSynchronize(c->lane2.stream);
+        (void)hipStreamDestroy(c->lane2.stream);
+    }
+    if (c->lane2.fork) (void)hipEventDestroy(c->lane2.fork);
+    if (c->lane2.done) (void)hipEventDestroy(c->lane2.done);
+    for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+        if (c->lane2.side[i]) {
+            (void)hipStreamSynchronize(c->lane2.side[i]);
+            (void)hipStreamDestroy(c->lane2.side[i]);
+        }
+        if (c->lane2.join[i]) (void)hipEventDestroy(c->lane2.join[i]);
+    }
     delete c->pack_pool;
     delete c->fin_pool;
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

@@ -15,7 +15,7 @@ namespace impl
 // ---- the chunked one-shot call ----
 
 constexpr uint64_t kChunkTargetPairs = 1u << 17;
-constexpr unsigned kMaxChunks = 8;
+constexpr unsigned kMaxChunks = 12;
 
 // Cuts the pair list into contiguous chunks and finds each chunk's table windows.  Returns false when chunking would not
 // pay: a small batch, or a pair list that jumps around the tables so that the windows overlap heavily (each chunk would
@@ -35,10 +35,19 @@ bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
     for (unsigned k = 0; k < C; ++k) weight[k] = std::min(k + 1, std::min(C - k, 3u));
     if (C >= 7) {
         // percent of the batch.  Packing is ~2.6x faster than sweeping, so a chunk may be up to 2.6x the one before it without the
-        // device running dry; the first is as small as a launch can usefully be, the last small enough for a short conversion tail
-        static const unsigned graded[] = {2, 6, 14, 26, 26, 18, 8};
-        C = 7;
-        weight.assign(graded, graded + 7);
+        // device running dry; the first is as small as a launch can usefully be, the last small enough for a short conversion tail.
+        // With two sweep lanes (compute_chunked) a chunk boundary costs next to nothing on the device, so the chunks are shorter:
+        // twelve measured best on config 2 (8.33 ms per call; ten 8.37, thirteen 8.41, sixteen 8.41, seven 8.54-8.72).
+        static const unsigned graded7[] = {2, 6, 14, 26, 26, 18, 8};
+        static const unsigned graded12[] = {2, 4, 6, 8, 10, 12, 12, 12, 10, 10, 8, 6};
+        if (phmm_hook("PHMM_CHUNK_ONE_LANE")) {
+            C = 7;
+            weight.assign(graded7, graded7 + 7);
+        }
+        else {
+            C = 12;
+            weight.assign(graded12, graded12 + 12);
+        }
     }
     if (const char *e = phmm_hook("PHMM_CHUNK_WEIGHTS")) {  // tuning aid: relative chunk sizes, e.g. "1,2,3,2,1"
         std::vector<unsigned> w;
@@ -149,12 +158,28 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         if (!c->chunk_done[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming));
     }
     if (!c->down) HIP_TRY(hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking));
+    // Two sweep lanes: a sweep's last workgroups leave most of the chip idle for a wave's duration ("How long a launch is"),
+    // and the next chunk's sweep, which depends on nothing but its own upload, can fill it -- if it sits in another hardware queue.
+    // Even chunks sweep on the context's streams, odd chunks on a second set.  Measured on config 2 with 16 hardware queues: device span
+    // of a call 8.17 -> 7.9 ms (resident pass: 7.65), and shorter chunks stop costing (twelve instead of seven: 8.65 -> 8.35 ms per call).
+    // PHMM_CHUNK_ONE_LANE=1 keeps everything on the context's streams.
+    const bool two_lanes = phmm_hook("PHMM_CHUNK_ONE_LANE") == nullptr;
+    if (two_lanes && !c->lane2.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->lane2.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->lane2.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->lane2.done, hipEventDisableTiming));
+        for (int i = 0; i < c->n_side; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->lane2.side[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->lane2.join[i], hipEventDisableTiming));
+        }
+    }
     hipStream_t up = c->side[phmm_context::kSideStreams - 1];  // not used by the sweeps (n_side defaults to 2 of 3)
     if (c->n_side >= phmm_context::kSideStreams) up = c->stream;
     hipStream_t down = c->down;
     HIP_TRY(hipStreamSynchronize(c->stream));  // nothing of an earlier call still reads the slots
     if (up != c->stream) HIP_TRY(hipStreamSynchronize(up));
     HIP_TRY(hipStreamSynchronize(down));
+    if (c->lane2.stream) HIP_TRY(hipStreamSynchronize(c->lane2.stream));
     const bool cross = b->pair_read == nullptr;
     const size_t n_chunks = plan.size();
     const bool trace = getenv("PHMM_PHASE_TIMING") != nullptr;  // tuning aid: host time line of the pipeline on stderr
@@ -340,6 +365,24 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
             explicit PhaseScope(PhaseClock *p) { g_phase = p; }
             ~PhaseScope() { g_phase = nullptr; }
         } phase_scope(trace ? &chunk_clock : nullptr);
+        // odd chunks: the second lane's stream set stands in for the context's while this chunk is enqueued (the upload stream is side[2]
+        // of the context either way: `up` was read before)
+        struct LaneSwap
+        {
+            phmm_context *c;
+            bool on;
+            void swap_sets()
+            {
+                std::swap(c->stream, c->lane2.stream);
+                std::swap(c->fork, c->lane2.fork);
+                for (int i = 0; i < c->n_side && i < phmm_context::kSideStreams - 1; ++i) {
+                    std::swap(c->side[i], c->lane2.side[i]);
+                    std::swap(c->join[i], c->lane2.join[i]);
+                }
+            }
+            LaneSwap(phmm_context *c_, bool on_) : c(c_), on(on_) { if (on) swap_sets(); }
+            ~LaneSwap() { if (on) swap_sets(); }
+        } lane_swap(c, two_lanes && async_upload && (k & 1));
         int rc = upload_into(c, &s, rb, opt);
         if (rc != PHMM_OK) return rc;
         // where the sums go: straight into the slot's pinned result block (the kernels write host memory over PCIe: no copy, no
@@ -356,7 +399,6 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         rc = impl::phmm_sweep(c, rb);
         if (rc != PHMM_OK) return rc;
         PHASE(4);
-        if (k + 1 == n_chunks) HIP_TRY(hipEventRecord(c->ev1, c->stream));
         if (direct) {
             HIP_TRY(hipEventRecord(c->chunk_done[slot], c->stream));
         }
@@ -381,6 +423,11 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
                     chunk_clock.us[4], chunk_clock.us[5]);
         }
     }
+    if (two_lanes && c->lane2.stream) {  // the device span of the call ends when both lanes are through
+        HIP_TRY(hipEventRecord(c->lane2.done, c->lane2.stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->lane2.done, 0));
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
     {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return collected >= enqueued || collector_rc != PHMM_OK; });

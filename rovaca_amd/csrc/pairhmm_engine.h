@@ -136,6 +136,13 @@ struct phmm_context
     hipEvent_t chunk_up[kChunkSlots] = {nullptr, nullptr, nullptr}, chunk_swept[kChunkSlots] = {nullptr, nullptr, nullptr},
                chunk_done[kChunkSlots] = {nullptr, nullptr, nullptr};
     hipStream_t down = nullptr;  // result copies of the chunked call
+    // the chunked call's second sweep lane (odd chunks): a stream set of its own, swapped in for the duration of a chunk's enqueue, so
+    // that one chunk's tail and the next one's head share the chip (compute_chunked)
+    struct SweepLane
+    {
+        hipStream_t stream = nullptr, side[kSideStreams] = {nullptr, nullptr, nullptr};
+        hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr}, done = nullptr;
+    } lane2;
     phmm_detail::HostPool *pack_pool = nullptr, *fin_pool = nullptr;  // helper threads of the two sides of that pipeline
     phmm_detail::BinScratch bin_scratch;       // host scratch of the length binning, kept between calls
     std::vector<hipEvent_t> timing;            // event pool of phmm_sweep_timed
