@@ -14,7 +14,7 @@ namespace impl
 
 // ---- the chunked one-shot call ----
 
-constexpr uint64_t kChunkTargetPairs = 1u << 17;
+constexpr uint64_t kChunkTargetPairs = 20000;  // pairs of the first chunk, roughly
 constexpr unsigned kMaxChunks = 12;
 
 // Cuts the pair list into contiguous chunks and finds each chunk's table windows.  Returns false when chunking would not
@@ -24,30 +24,26 @@ bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
 {
     const bool cross = b->pair_read == nullptr;
     const uint64_t n = cross ? (uint64_t)b->n_reads * b->n_haps : b->n_pairs;
-    if (n < kChunkedMinPairs || b->n_reads == 0 || b->n_haps == 0) return false;
+    if (n < chunked_min_pairs() || b->n_reads == 0 || b->n_haps == 0) return false;
     if (const char *e = phmm_hook("PHMM_NO_CHUNKED_COMPUTE")) {  // tests
         if (e[0] != '0') return false;
     }
-    // Chunk sizes rise and fall: the first chunk's packing and the last chunk's conversion are the only host work the device
-    // cannot hide, so those two are small -- 2 % and 8 % of the batch from seven chunks on.
-    unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(2, n / kChunkTargetPairs + 2));
+    // Chunk sizes rise and fall: the first chunk's packing and the last chunk's conversion are the only host work the device cannot
+    // hide, so those are small; in between, packing is ~2.6x faster than sweeping, so a chunk may be up to 2.6x the one before it without
+    // the device running dry.  With two sweep lanes (compute_chunked) a chunk boundary costs next to nothing on the device, so the chunks
+    // are short: about 20 000 pairs for the first, between four and twelve chunks.  Measured on config 2's pairs, host buffers to log10,
+    // against one upload + one sweep: 30 000 pairs 0.57 -> 0.52 ms (1:2:2:1), 100 000 1.75 -> 1.12 (1:2:3:2:1), 300 000 4.71 -> 2.73,
+    // 500 000 7.13 -> 4.32, 1 000 000 8.65 (seven chunks, one lane) -> 8.25 (twelve: 1:2:3:4:5:6:6:6:6:5:4:3; ten 8.37, sixteen 8.41).
+    unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(4, n / kChunkTargetPairs));
     std::vector<unsigned> weight(C);
-    for (unsigned k = 0; k < C; ++k) weight[k] = std::min(k + 1, std::min(C - k, 3u));
-    if (C >= 7) {
-        // percent of the batch.  Packing is ~2.6x faster than sweeping, so a chunk may be up to 2.6x the one before it without the
-        // device running dry; the first is as small as a launch can usefully be, the last small enough for a short conversion tail.
-        // With two sweep lanes (compute_chunked) a chunk boundary costs next to nothing on the device, so the chunks are shorter:
-        // twelve measured best on config 2 (8.33 ms per call; ten 8.37, thirteen 8.41, sixteen 8.41, seven 8.54-8.72).
+    {
+        const unsigned P = (C + 1) / 2;  // plateau
+        for (unsigned k = 0; k < C; ++k) weight[k] = std::min(std::min(k + 1, P), (C - k) + P / 2 - 1);
+    }
+    if (phmm_hook("PHMM_CHUNK_ONE_LANE") && C >= 7) {  // the plan of the one-lane form (A/B)
         static const unsigned graded7[] = {2, 6, 14, 26, 26, 18, 8};
-        static const unsigned graded12[] = {2, 4, 6, 8, 10, 12, 12, 12, 10, 10, 8, 6};
-        if (phmm_hook("PHMM_CHUNK_ONE_LANE")) {
-            C = 7;
-            weight.assign(graded7, graded7 + 7);
-        }
-        else {
-            C = 12;
-            weight.assign(graded12, graded12 + 12);
-        }
+        C = 7;
+        weight.assign(graded7, graded7 + 7);
     }
     if (const char *e = phmm_hook("PHMM_CHUNK_WEIGHTS")) {  // tuning aid: relative chunk sizes, e.g. "1,2,3,2,1"
         std::vector<unsigned> w;
@@ -437,6 +433,7 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
     if (enqueued != n_chunks) return fail(PHMM_E_INVALID, "phmm_compute: the chunk pipeline stopped early");
     if (stats) {
         float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(c->ev1));  // recorded behind the join of the two lanes: the last chunk's results can be in before it
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         total.kernel_ms = ms;
         *stats = total;

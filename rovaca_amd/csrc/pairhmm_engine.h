@@ -268,7 +268,12 @@ struct ChunkWindow
     uint32_t r0 = 0, r1 = 0, h0 = 0, h1 = 0;  // reads [r0, r1), haplotypes [h0, h1)
     uint64_t rb0 = 0, rb1 = 0, hb0 = 0, hb1 = 0;  // byte ranges of the two tables
 };
-constexpr uint64_t kChunkedMinPairs = 1u << 19;  // below this one upload + one sweep is as fast
+constexpr uint64_t kChunkedMinPairs = 40000;  // below this one upload + one sweep is as fast (2^19 until the pipeline had two sweep lanes)
+static inline uint64_t chunked_min_pairs()
+{
+    if (const char *e = phmm_hook("PHMM_CHUNKED_MIN_PAIRS")) return (uint64_t)std::max(1, atoi(e));  // tuning
+    return kChunkedMinPairs;
+}
 
 namespace phmm_detail
 {
