@@ -255,12 +255,39 @@ def test_config5_full_size_properties(engine, monkeypatch):
     assert np.array_equal(nraw.view(np.uint32), raw[sub].view(np.uint32)) and np.array_equal(nl10, l10[sub])
 
 
+@pytest.mark.parametrize("n_regions,one_lane", [(41, False), (75, False), (130, True), (330, False)])
+def test_mid_size_one_shot_calls_take_the_chunk_pipeline_too(engine, n_regions, one_lane, monkeypatch):
+    # from 40 000 pairs on a one-shot call is cut into four to twelve chunks that alternate between two sweep lanes (two stream sets of
+    # the context; PHMM_CHUNK_ONE_LANE keeps one): same bits as one upload + one sweep and as the oracle, with a noisy batch that sends
+    # pairs through the fp64 re-run of both lanes, and called twice through the same context (slots and lanes are reused)
+    b = synth.make_batch(seed=700 + n_regions, n_regions=n_regions, reads=40, haps=25, read_len=(60, 200), hap_len=(150, 400),
+                         sub_rate=0.06 if n_regions == 75 else 0.01, qual=30 if n_regions == 75 else "illumina")
+    assert b.n_pairs >= 40000
+    if one_lane:
+        monkeypatch.setenv("PHMM_CHUNK_ONE_LANE", "1")
+    raw, l10, st = engine.compute(b)
+    raw2, l10_2, _ = engine.compute(b)
+    assert np.array_equal(raw.view(np.uint32), raw2.view(np.uint32)) and np.array_equal(l10, l10_2, equal_nan=True)
+    monkeypatch.setenv("PHMM_NO_CHUNKED_COMPUTE", "1")
+    praw, pl10, pst = engine.compute(b)
+    monkeypatch.delenv("PHMM_NO_CHUNKED_COMPUTE")
+    assert np.array_equal(raw.view(np.uint32), praw.view(np.uint32)) and np.array_equal(l10, pl10, equal_nan=True)
+    assert int(st.n_rescued) == int(pst.n_rescued) and int(st.cells) == b.cells()
+    if n_regions == 75:
+        assert int(st.n_rescued) > 100
+    idx = np.sort(np.random.default_rng(n_regions).choice(b.n_pairs, 2000, replace=False))
+    oraw, ol10, oresc = oracle.batch(b.subset(idx), n_threads=8)
+    assert np.array_equal(raw[idx].view(np.uint32), oraw.view(np.uint32)) and np.array_equal(l10[idx][~oresc], ol10[~oresc])
+    if oresc.any():
+        assert np.abs(l10[idx][oresc] - ol10[oresc]).max() < 1e-9
+
+
 def test_chunked_one_shot_compute_is_the_plain_one(engine, monkeypatch):
     # phmm_compute cuts a big batch into chunks (binning, packing and upload of chunk k + 1 under the sweep of chunk k, host
     # log10 of chunk k - 1 meanwhile): same bits as one upload + one sweep, for an explicit pair list, for the full cross
     # product, with device-side read preparation, and for a pair list that jumps around the tables (no chunking then)
     b = synth.make_batch(seed=52, n_regions=560, reads=40, haps=25, read_len=(60, 200), hap_len=(150, 400))
-    assert b.n_pairs >= 1 << 19
+    assert b.n_pairs >= 1 << 19  # twelve chunks
     raw, l10, st = engine.compute(b)
     assert int(st.cells) == b.cells()
     monkeypatch.setenv("PHMM_NO_CHUNKED_COMPUTE", "1")
