@@ -4,6 +4,9 @@ There is no fallback of any kind: if the HIP library is missing or no device is 
 """
 import ctypes as C
 import os
+
+# before the process's first HIP call: the engines keep more streams busy than the runtime's default of 4 hardware queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import subprocess
 
 import numpy as np

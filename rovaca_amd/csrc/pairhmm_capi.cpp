@@ -69,11 +69,11 @@ int phmm_create(int device_id, void *stream, phmm_context **out)
 {
     if (!out || device_id < 0) return fail(PHMM_E_INVALID, "phmm_create: bad arguments");
     *out = nullptr;
-    // A context drives up to six streams (sweep, three side streams, upload, download) and a process usually holds several contexts;
-    // the HIP runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, and streams that share one take turns.
-    // Ask for 16 unless the user chose -- effective only when this is the process's first HIP call (the adapter's
-    // init_pairhmm_ptr_gpu and bench.py set it earlier for that reason).
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // A context drives up to ten streams (two sweep lanes of three, upload, download) and a process usually holds several contexts; the
+    // HIP runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, and streams that share one take turns.  The
+    // one-shot pipeline and the adapters are built for 16: the variable has to be in the environment before the process's first HIP
+    // call, which is not a library's to arrange (setenv races with other threads' getenv) -- the adapter's init_pairhmm_ptr_gpu does it
+    // on the main thread before the workers exist, the Python bindings at import, bench.py at start; README.md has the line for others.
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(PHMM_E_NO_DEVICE, "phmm_create: no HIP device visible (this engine has no CPU fallback)");

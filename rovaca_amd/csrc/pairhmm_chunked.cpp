@@ -348,7 +348,7 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         // has handed out its last workgroup -- small kernels of another queue are starved by a grid that fills the chip -- and the
         // sweep behind it would wait with it: 90-110 us of a drained chip at every chunk boundary (rocprofv3 time line, round 3).
         opt.setup_stream = c->stream;
-        // Since the process asks for 16 hardware queues (phmm_create; the runtime's default of 4 made the upload stream share a queue
+        // Built for 16 hardware queues (GPU_MAX_HW_QUEUES, see phmm_create; the runtime's default of 4 made the upload stream share a queue
         // with the sweeps, which is what the two findings above were): copy and set-up launch both on the upload stream, the sweep behind
         // an event, and the packing thread never waits for a copy.  8.62-8.68 ms per call on config 2 against 8.74-8.75 with the
         // synchronous copy + set-up on the sweep stream (PHMM_CHUNK_SYNC_UPLOAD=1 keeps that form; with 4 queues the two are equal).

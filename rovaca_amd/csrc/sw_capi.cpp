@@ -353,7 +353,6 @@ const char *swhip_last_error(void) { return g_err; }
 
 int swhip_create(int device_id, void *stream, swhip_context **out)
 {
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);  // as phmm_create (pairhmm_capi.cpp): streams beyond the runtime's 4 hardware queues take turns
     if (!out || device_id < 0) return fail(SWHIP_E_INVALID, "swhip_create: bad arguments");
     *out = nullptr;
     int n = 0;

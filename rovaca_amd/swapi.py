@@ -3,6 +3,9 @@ No CPU fallback: the library refuses to create a context without a GPU, and this
 import ctypes as C
 import os
 
+# before the process's first HIP call: the engines keep more streams busy than the runtime's default of 4 hardware queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
