@@ -12,7 +12,15 @@ cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/r3_evidence; rm -rf $OUT; mkdir -p $OUT
   for d in 1 4; do for th in 1 30 128; do
     echo "== PairHMM + realignment: $th workers, $d in flight"
     timeout -k 5 170 rovaca_amd/lib/adapter_bench $th 1000 48 9 1 $d 2>&1
-  done; done; } > $OUT/adapter.txt 2>&1
+  done; done
+  for sw in 0 1; do for d in 1 4; do for th in 1 8 30 64; do
+    echo "== regions of mixed shape (ADAPTER_BENCH_MIXED=1), realignment $sw: $th workers, $d in flight"
+    ADAPTER_BENCH_MIXED=1 timeout -k 5 170 rovaca_amd/lib/adapter_bench $th 1000 48 9 $sw $d 2>&1
+  done; done; done; } > $OUT/adapter.txt 2>&1
+{ for cfg in "1 1" "30 1" "30 4"; do set -- $cfg
+    echo "== PairHMM + realignment with the host phases of both seams: $1 workers, $2 in flight"
+    ADAPTER_BENCH_PHASES=1 timeout -k 5 170 rovaca_amd/lib/adapter_bench $1 1000 48 9 1 $2 2>&1
+  done; } > $OUT/sw_host_profile.txt 2>&1
 python tools/measure_stage_latency.py > $OUT/stage_latency.txt 2>&1
 python tools/measure_e2e_timeline.py > $OUT/e2e_timeline.txt 2>&1
 python tools/bench_c5_shapes.py > $OUT/c5_shapes.txt 2>&1
