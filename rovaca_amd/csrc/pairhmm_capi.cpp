@@ -948,11 +948,14 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
     {
         std::vector<ChunkWindow> plan;
         const uint64_t n_all = b->pair_read ? b->n_pairs : (uint64_t)b->n_reads * b->n_haps;
-        if (n_all >= chunked_min_pairs()) {  // the helper threads of the chunk pipeline (also used by the plan itself)
-            if (!c->pack_pool) c->pack_pool = new phmm_detail::HostPool(std::max(1u, host_threads()) - 1u);
-            if (!c->fin_pool) c->fin_pool = new phmm_detail::HostPool(3);
-        }
-        phmm_detail::PoolScope pool(n_all >= chunked_min_pairs() ? c->pack_pool : nullptr);
+        // helper threads of the chunk pipeline (also used by the plan itself), made on a context's first chunked call: all the cores for
+        // a batch of half a million pairs or more, three helpers for a mid-size one (a context per worker thread must not bring a
+        // dozen threads each along for the odd large region)
+        const bool chunkable = n_all >= chunked_min_pairs();
+        if (chunkable && !c->pack_pool)
+            c->pack_pool = new phmm_detail::HostPool(n_all >= (1u << 19) ? std::max(1u, host_threads()) - 1u : std::min(3u, std::max(1u, host_threads()) - 1u));
+        if (chunkable && !c->fin_pool) c->fin_pool = new phmm_detail::HostPool(3);
+        phmm_detail::PoolScope pool(chunkable ? c->pack_pool : nullptr);
         const bool tables_ok = b->read_bases && b->read_qual && b->read_off && b->read_len && b->hap_bases && b->hap_off && b->hap_len &&
                                ((b->pair_read == nullptr) == (b->pair_hap == nullptr)) && (b->prep ? b->prep->read_mapq != nullptr : true);
         if (tables_ok && impl::plan_chunks(b, plan)) {

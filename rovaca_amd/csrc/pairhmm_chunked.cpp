@@ -239,7 +239,7 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
                 n_resc.fetch_add(resc, std::memory_order_relaxed);
             };
             if (n >= (1u << 14))
-                parallel_ranges(n, c->fin_pool->helpers() + 1u, finalize);
+                parallel_ranges(n, (c->fin_pool ? c->fin_pool->helpers() : 0u) + 1u, finalize);
             else
                 finalize(0, n, 0);
         }
