@@ -952,8 +952,14 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
         // a batch of half a million pairs or more, three helpers for a mid-size one (a context per worker thread must not bring a
         // dozen threads each along for the odd large region)
         const bool chunkable = n_all >= chunked_min_pairs();
-        if (chunkable && !c->pack_pool)
-            c->pack_pool = new phmm_detail::HostPool(n_all >= (1u << 19) ? std::max(1u, host_threads()) - 1u : std::min(3u, std::max(1u, host_threads()) - 1u));
+        if (chunkable) {
+            const unsigned all = std::max(1u, host_threads()) - 1u, want = n_all >= (1u << 19) ? all : std::min(3u, all);
+            if (c->pack_pool && c->pack_pool->helpers() < want) {  // a large batch after mid-size ones: the pool grows once
+                delete c->pack_pool;
+                c->pack_pool = nullptr;
+            }
+            if (!c->pack_pool) c->pack_pool = new phmm_detail::HostPool(want);
+        }
         if (chunkable && !c->fin_pool) c->fin_pool = new phmm_detail::HostPool(3);
         phmm_detail::PoolScope pool(chunkable ? c->pack_pool : nullptr);
         const bool tables_ok = b->read_bases && b->read_qual && b->read_off && b->read_len && b->hap_bases && b->hap_off && b->hap_len &&
