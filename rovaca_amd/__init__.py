@@ -12,3 +12,11 @@ def kernel_source_id():
     for name in ("pairhmm_kernels.hip", "pairhmm_device.h"):
         h.update(open(os.path.join(_HERE, "csrc", name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def sw_kernel_source_id():
+    """The same for the Smith-Waterman kernel (profiles/sw_counters.json)."""
+    h = hashlib.sha256()
+    for name in ("sw_kernels.hip", "sw_device.h"):
+        h.update(open(os.path.join(_HERE, "csrc", name), "rb").read())
+    return h.hexdigest()[:16]

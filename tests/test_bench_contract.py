@@ -58,6 +58,20 @@ def test_committed_pmc_counters_belong_to_the_committed_kernels():
     assert pj["c2"] > 0 and pj["c2_valu_wave_instructions"] > 0 and "pairhmm_systolic" in pj["c2_kernel"]
 
 
+def test_committed_smith_waterman_counters_belong_to_the_committed_kernel():
+    from rovaca_amd import sw_kernel_source_id
+    pj = json.load(open(os.path.join(ROOT, "profiles", "sw_counters.json")))
+    assert pj.get("kernel_source_id") == sw_kernel_source_id(), "stale PMC counters: re-run tools/profile_round.sh and tools/summarize_profiles.py"
+    assert pj["valu_wave_instructions"] > 0 and "sw_kernel" in pj["kernel"]
+
+
+@pytest.mark.gpu
+def test_smith_waterman_line_has_its_issue_roofline():
+    d = _run("--config", "sw", "--no-cpu-baseline")
+    assert d["metric"] == "Smith-Waterman GCUPS" and d["value"] > 0
+    assert 0.2 < d["roofline_issue"]["frac"] <= 1.0 and d["roofline"]["traffic"] > d["roofline"]["algorithmic_bytes"]  # the backtrack flags
+
+
 @pytest.mark.gpu
 def test_device_line_carries_the_measured_traffic():
     d = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-adapter")

@@ -123,4 +123,12 @@ if os.path.exists(f):
                 % (mean["WRITE_SIZE"] * 1024 / 1e9, mean["WRITE_SIZE"] * 1024 / ms / 1e9, 100 * mean["WRITE_SIZE"] * 1024 / ms / 1e9 / 8),
                 "       the algorithmic input/output (len1 + len2 in, 20 B + CIGAR out, ~0.6 KB per alignment) is 0.2 % of HBM."]
     open(os.path.join(dst, "%s_pmc_summary.txt" % tag.replace("final", "sw")), "w").write("\n".join(txt) + "\n")
+    if valu:
+        # read by bench.py --config sw for roofline_issue / roofline.traffic (gated on the kernel sources, like hbm_traffic.json)
+        from rovaca_amd import sw_kernel_source_id
+        json.dump({"kernel_source_id": sw_kernel_source_id(), "kernel": hot["Name"].replace("void ", "").split("(")[0],
+                   "valu_wave_instructions": int(valu), "waves": int(waves),
+                   "fetch_raw_bytes": int(mean.get("FETCH_SIZE", 0.0) * 1024), "write_bytes": int(mean.get("WRITE_SIZE", 0.0) * 1024),
+                   "_note": "per launch of bench.py --config sw (48 000 alignments, 150-153 x 400), from profiles/%s_pmc_summary.txt" % tag.replace("final", "sw")},
+                  open(os.path.join(dst, "sw_counters.json"), "w"), indent=1)
     print("\n".join(txt))
