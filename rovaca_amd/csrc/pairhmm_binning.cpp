@@ -96,7 +96,10 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
         std::vector<uint32_t> &hist = scratch.hist, &slot = scratch.slot;
         hist.assign(table + 1, 0);
         slot.resize(n_pairs);
-        const unsigned T = (n_pairs >= kParallelMinPairs && table <= (1u << 16)) ? host_threads() : 1u;
+        // (with a helper pool current -- the chunked call -- handing out parts costs microseconds, so chunks of tens of thousands of pairs
+        // are split too: a chunk of 118 000 mixed-length pairs took 0.5-1.0 ms to bin on one thread, longer than its sweep)
+        const uint64_t par_min = phmm_detail::t_pool ? (1u << 15) : kParallelMinPairs;
+        const unsigned T = (n_pairs >= par_min && table <= (1u << 16)) ? host_threads() : 1u;
         std::vector<std::vector<uint32_t>> th_hist(T > 1 ? T : 0);
         std::vector<uint64_t> th_cells(T, 0);
         std::vector<uint32_t> th_rmax((size_t)T * kClasses, 0);

@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rovaca_amd import capi, synth
 
-b = synth.make_config("c2")
+b = synth.make_config(sys.argv[1] if len(sys.argv) > 1 else "c2")
 eng = capi.Engine(0)
 out = (np.zeros(b.n_pairs, np.float32), np.zeros(b.n_pairs, np.float64))
 os.environ.pop("PHMM_PHASE_TIMING", None)
