@@ -966,9 +966,11 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
                                ((b->pair_read == nullptr) == (b->pair_hap == nullptr)) && (b->prep ? b->prep->read_mapq != nullptr : true);
         if (tables_ok && impl::plan_chunks(b, plan)) {
             const int rc = impl::compute_chunked(c, b, plan, out_raw_f32, out_log10, stats);
-            if (rc == PHMM_OK && stats)
-                stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            return rc;
+            if (rc != kChunkedUnavailable) {
+                if (rc == PHMM_OK && stats)
+                    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                return rc;
+            }
         }
     }
     if (!c->scratch) {

@@ -252,7 +252,11 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         return PHMM_OK;
     };
 
-    std::thread collector([&] {
+    // (a process at its thread limit -- 128 workers each with a context of their own -- cannot start the collector: nothing has been
+    // enqueued yet, the caller takes the one-upload path instead)
+    std::thread collector;
+    try {
+        collector = std::thread([&] {
         (void)hipSetDevice(c->device);
         phmm_detail::PoolScope pool(c->fin_pool);
         for (size_t k = 0; k < n_chunks; ++k) {
@@ -278,7 +282,12 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
             }
             cv.notify_all();
         }
-    });
+        });
+    }
+    catch (const std::system_error &) {
+        return kChunkedUnavailable;
+    }
+
     struct Joiner  // whichever way this function returns, the collector is told and joined first
     {
         std::thread &t;

@@ -269,6 +269,7 @@ struct ChunkWindow
     uint64_t rb0 = 0, rb1 = 0, hb0 = 0, hb1 = 0;  // byte ranges of the two tables
 };
 constexpr uint64_t kChunkedMinPairs = 40000;  // below this one upload + one sweep is as fast (2^19 until the pipeline had two sweep lanes)
+constexpr int kChunkedUnavailable = -1000;  // compute_chunked could not start (no thread to be had): not an error, take the plain path
 static inline uint64_t chunked_min_pairs()
 {
     if (const char *e = phmm_hook("PHMM_CHUNKED_MIN_PAIRS")) return (uint64_t)std::max(1, atoi(e));  // tuning
