@@ -49,7 +49,6 @@ template <int K, int G>
 __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
 {
     extern __shared__ uint8_t lds_seq1[];  // [alignments per block][lds_stride]: seq1 of each alignment
-    __shared__ uint32_t cap_lds[(kBlockThreads / G) * K];  // per alignment: the K new H values of the lane that holds column ncol
     constexpr uint32_t W = (K + 7) / 8;  // backtrack words a lane produces per step
     // they are stored as W32 full dwords plus a tail of 1, 2 or 4 bytes for the last K % 8 cells, in two arrays
     // ([step][lane][W32] dwords, then [step][lane] tails): the kernel is bound by these writes, so 10 columns per lane cost
@@ -124,7 +123,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
             next1 = (steady || (valid && ni >= 1 && ni <= nrow)) ? (uint32_t)my1[ni - 1] : 0u;
         }
         if (active) {
-            uint32_t hl = inH, e = inE, hd = diag0;
+            uint32_t hl = inH, e = inE, hd = diag0, h_ncol = 0;
             uint32_t words[W];
 #pragma unroll
             for (uint32_t w = 0; w < W; ++w) words[w] = 0;
@@ -172,6 +171,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                     : "vcc");
                 words[k / 8] = acc;
                 hd = Hp[k];  // the diagonal of the next column
+                h_ncol = (uint32_t)k == kc ? h11 : h_ncol;
                 Hp[k] = h11;
                 F[k] = f11;
                 hl = h11;
@@ -188,14 +188,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 if constexpr (TAILB == 2) reinterpret_cast<uint16_t *>(bt_tail)[slot] = (uint16_t)words[W - 1];
                 if constexpr (TAILB == 4) reinterpret_cast<uint32_t *>(bt_tail)[slot] = words[W - 1];
             }
-            if (lane == lc) {  // column ncol, every row: the lane that holds it parks its K new values and reads the one it needs
-                // (a dynamic register index does not exist; K selects per step in every lane cost 6 % of the kernel, K LDS writes
-                // by one lane per alignment go through a port the sweep does not use)
-                volatile uint32_t *cap = cap_lds + (threadIdx.x / G) * K;
-#pragma unroll
-                for (int k = 0; k < K; ++k) cap[k] = Hp[k];
-                lastcol[i - 1] = (int32_t)(cap[kc] - kBias);
-            }
+            if (lane == lc) lastcol[i - 1] = (int32_t)(h_ncol - kBias);  // column ncol, every row
             if (!steady && i == nrow) {  // row nrow, every column
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
