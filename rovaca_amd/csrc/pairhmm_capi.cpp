@@ -351,6 +351,7 @@ int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const U
     {
         const int rc = phmm_detail::bin_pairs(b, cross, n_pairs, opt.read_bias, opt.hap_bias, pr, ph, order, c->bin_scratch, rb->bins, &cells);
         if (rc != PHMM_OK) return rc;
+        merge_striped_bins_of_one_shape(rb->bins);
     }
     rb->cells = cells;
     PHASE(2);

@@ -205,6 +205,7 @@ static int stage_plan(phmm_stage *st, uint32_t n_regions, uint32_t n_reads, uint
     const int rc = phmm_detail::bin_regions(v.regions, n_regions, v.read_len, n_reads, v.hap_len, n_haps, st->slot_first.data(),
                                             st->pair_first.data(), bins, cells, &n_pairs);
     if (rc != PHMM_OK) return rc;
+    merge_striped_bins_of_one_shape(bins);
     if (n_pairs > k.max_pairs) return fail(PHMM_E_INVALID, "phmm_stage_submit: %llu pairs exceed the stage's capacity of %u", (unsigned long long)n_pairs, k.max_pairs);
     st->pair_first[n_regions] = (uint32_t)n_pairs;
     st->n_regions = n_regions;
