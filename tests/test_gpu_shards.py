@@ -249,6 +249,12 @@ def test_config5_full_size_properties(engine, monkeypatch):
     perm = np.random.default_rng(5).permutation(b.n_pairs)
     praw, pl10, _ = engine.compute(b.subset(perm))
     assert np.array_equal(praw.view(np.uint32), raw[perm].view(np.uint32)) and np.array_equal(pl10, l10[perm])
+    # the three size ranges of this batch all get four waves of 64 lanes and are therefore one launch, longest pair first; as three
+    # launches (the A/B hook) the bits are the same
+    monkeypatch.setenv("PHMM_NO_STRIPED_MERGE", "1")
+    sraw, sl10, sst = engine.compute(b)
+    monkeypatch.delenv("PHMM_NO_STRIPED_MERGE")
+    assert np.array_equal(sraw.view(np.uint32), raw.view(np.uint32)) and np.array_equal(sl10, l10) and int(sst.n_launches) > int(st.n_launches)
     monkeypatch.setenv("PHMM_NO_EARLY_EXIT", "1")
     sub = np.arange(0, b.n_pairs, 4)  # the unshortened sweep is several times slower: a quarter of the pairs
     nraw, nl10, _ = engine.compute(b.subset(sub))
