@@ -93,6 +93,9 @@ typedef struct phmm_stats {
 
 /* ---- life cycle (replaces the kernel binding half of init_pairhmm_ptr, pairhmm_engine.cpp:43-52) ---- */
 int phmm_abi_version(void);
+/* Which device code this library was linked from: a hash of the sweep kernels' sources and compile flags (rovaca_amd/csrc/Makefile).
+   Measurement hygiene only -- profiles/ records it next to the PMC counters, bench.py compares. */
+const char *phmm_kernel_build_id(void);
 int phmm_device_count(void);
 /* device_id >= 0.  stream: a hipStream_t to run on, or NULL to create a private one.  One context drives ONE device (its
  * stream set, staging and tables live there); for several devices see phmm_create_multi below. */

@@ -65,6 +65,7 @@ typedef struct swhip_stats {
 } swhip_stats;
 
 int swhip_abi_version(void);
+const char *swhip_kernel_build_id(void); /* hash of the kernel sources and compile flags this library was linked from */
 int swhip_device_count(void); /* visible HIP devices, 0 without a GPU */
 int swhip_create(int device_id, void *stream, swhip_context **out); /* no CPU fallback: fails without a GPU */
 void swhip_destroy(swhip_context *ctx);

@@ -25,7 +25,7 @@ EXPORTS = ("phmm_abi_version", "phmm_device_count", "phmm_create", "phmm_destroy
            "phmm_multi_upload", "phmm_multi_sweep", "phmm_multi_synchronize", "phmm_multi_sweep_timed", "phmm_multi_download",
            "phmm_multi_shard_cells", "phmm_multi_release", "phmm_marginalize", "phmm_create_cpu", "phmm_backend_name", "phmm_plan_slices",
            "phmm_create_multi_cpu", "phmm_compute_regions", "phmm_stage_create", "phmm_stage_destroy", "phmm_stage_get_view", "phmm_stage_submit", "phmm_stage_wait",
-           "phmm_stage_pair_first", "phmm_stage_log10", "phmm_plan_bins", "phmm_plan_region_bins")
+           "phmm_stage_pair_first", "phmm_stage_log10", "phmm_plan_bins", "phmm_plan_region_bins", "phmm_kernel_build_id")
 
 
 class PhmmBatch(C.Structure):
@@ -89,6 +89,7 @@ def lib():
     L.phmm_destroy.argtypes = [C.c_void_p]
     L.phmm_destroy.restype = None
     L.phmm_last_error.restype = C.c_char_p
+    L.phmm_kernel_build_id.restype = C.c_char_p
     L.phmm_compute.argtypes = [C.c_void_p, C.POINTER(PhmmBatch), C.c_void_p, C.c_void_p, C.POINTER(PhmmStats)]
     L.phmm_compute.restype = C.c_int
     L.phmm_upload.argtypes = [C.c_void_p, C.POINTER(PhmmBatch), C.POINTER(C.c_void_p)]

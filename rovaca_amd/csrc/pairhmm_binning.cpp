@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 
 namespace phmm_detail
@@ -11,20 +12,25 @@ int fail(int code, const char *fmt, ...);  // pairhmm_capi.cpp: sets the calling
 }
 using phmm_detail::fail;
 
-extern char **environ;
 namespace phmm_detail
 {
 thread_local int t_hooks = -1;
 thread_local HostPool *t_pool = nullptr;
-bool any_phmm_variable()
+thread_local bool t_serial = false;
+bool test_hooks_enabled()
 {
-    for (char **e = environ; e && *e; ++e)
-        if ((*e)[0] == 'P' && (*e)[1] == 'H' && (*e)[2] == 'M' && (*e)[3] == 'M' && (*e)[4] == '_') return true;
-    return false;
+    const char *m = getenv("PHMM_ENABLE_TEST_HOOKS");
+    return m && m[0] && !(m[0] == '0' && m[1] == 0);
 }
 }  // namespace phmm_detail
-const char *phmm_hook(const char *name) { return phmm_detail::t_hooks == 0 ? nullptr : getenv(name); }
+const char *phmm_hook(const char *name)
+{
+    if (phmm_detail::t_hooks == 0) return nullptr;
+    if (phmm_detail::t_hooks < 0 && !phmm_detail::test_hooks_enabled()) return nullptr;
+    return getenv(name);
+}
 
+bool ragged_launches_for(bool uniform_gcp) { return uniform_gcp && phmm_hook("PHMM_NO_RAGGED") == nullptr; }
 bool queue_per_class_for(uint64_t n_pairs) { return n_pairs > kQueuePerClassMinPairs || phmm_hook("PHMM_FORCE_QUEUE_PER_CLASS") != nullptr; }
 
 namespace phmm_detail
@@ -68,7 +74,7 @@ static void merge_small_bins(std::vector<Bin> &bins, bool queue_per_class)
 }
 
 int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_bias, uint32_t hap_bias, uint32_t *pr, uint32_t *ph,
-              uint32_t *order, BinScratch &scratch, std::vector<Bin> &bins, uint64_t *cells_out)
+              uint32_t *order, BinScratch &scratch, std::vector<Bin> &bins, uint64_t *cells_out, bool ride_along)
 {
     const bool queue_per_class = queue_per_class_for(n_pairs);
     uint32_t max_hap = 0;
@@ -92,6 +98,16 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
     }
     uint64_t cells = 0;
     const uint64_t table = (uint64_t)n_used * hrange;
+    const bool bin_trace = n_pairs >= 4096 && getenv("PHMM_PHASE_TIMING") != nullptr;  // tuning aid: where the binning's time goes, on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    double lap_us[6] = {0};
+    auto lap = [&](int i) {
+        if (!bin_trace) return;
+        const auto n = std::chrono::steady_clock::now();
+        lap_us[i] += std::chrono::duration<double, std::micro>(n - t_prev).count();
+        t_prev = n;
+    };
+    lap(0);
     if (table <= std::max<uint64_t>(4 * n_pairs, 1u << 16)) {
         std::vector<uint32_t> &hist = scratch.hist, &slot = scratch.slot;
         hist.assign(table + 1, 0);
@@ -99,7 +115,7 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
         // (with a helper pool current -- the chunked call -- handing out parts costs microseconds, so chunks of tens of thousands of pairs
         // are split too: a chunk of 118 000 mixed-length pairs took 0.5-1.0 ms to bin on one thread, longer than its sweep)
         const uint64_t par_min = phmm_detail::t_pool ? (1u << 15) : kParallelMinPairs;
-        const unsigned T = (n_pairs >= par_min && table <= (1u << 16)) ? host_threads() : 1u;
+        const unsigned T = (n_pairs >= par_min && table <= (1u << 16) && !phmm_detail::t_serial) ? host_threads() : 1u;
         std::vector<std::vector<uint32_t>> th_hist(T > 1 ? T : 0);
         std::vector<uint64_t> th_cells(T, 0);
         std::vector<uint32_t> th_rmax((size_t)T * kClasses, 0);
@@ -135,14 +151,17 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
             }
             th_cells[t] = cells_t;
         };
+        lap(1);
         if (T > 1) {
             for (auto &v : th_hist) v.assign(table, 0);
             parallel_ranges(n_pairs, T, count_range);
+            lap(2);
             for (unsigned t = 0; t < T; ++t)
                 for (uint64_t i = 0; i < table; ++i) hist[i + 1] += th_hist[t][i];
         }
         else {
             count_range(0, n_pairs, 0);
+            lap(2);
         }
         if (bad_pair.load() != UINT64_MAX)
             return fail(PHMM_E_INVALID, "phmm_upload: pair %llu indexes outside the tables", (unsigned long long)bad_pair.load());
@@ -172,6 +191,7 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
             }
             k = k_end;
         }
+        lap(3);
         if (T > 1) {
             // stable scatter: inside a slot thread 0's pairs come first, then thread 1's, ... -- the order one thread gives
             for (uint64_t i = 0; i < table; ++i) {
@@ -182,6 +202,7 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
                     run += cnt;
                 }
             }
+            lap(4);
             parallel_ranges(n_pairs, T, [&](uint64_t lo, uint64_t hi, unsigned t) {
                 uint32_t *start = th_hist[t].data();
                 for (uint64_t p = lo; p < hi; ++p) order[start[slot[p]]++] = (uint32_t)p;
@@ -190,6 +211,10 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
         else {
             for (uint64_t p = 0; p < n_pairs; ++p) order[hist[slot[p]]++] = (uint32_t)p;
         }
+        lap(5);
+        if (bin_trace)
+            fprintf(stderr, "phmm bin: %llu pairs, table %llu, %u threads: classes %.0f alloc %.0f count %.0f merge+bins %.0f offsets %.0f scatter %.0f us\n",
+                    (unsigned long long)n_pairs, (unsigned long long)table, T, lap_us[0], lap_us[1], lap_us[2], lap_us[3], lap_us[4], lap_us[5]);
     }
     else {
         // sparse length distribution: comparison sort on (class, length, index)
@@ -228,13 +253,14 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
             i = j;
         }
     }
-    merge_small_bins(bins, queue_per_class);
+    if (ride_along) merge_small_bins(bins, queue_per_class);
     *cells_out = cells;
     return PHMM_OK;
 }
 
 int bin_regions(const phmm_region *regions, uint32_t n_regions, const uint32_t *read_len, uint32_t n_reads, const uint32_t *hap_len,
-                uint32_t n_haps, uint32_t *slot_first, uint32_t *pair_first, std::vector<Bin> &bins, uint64_t *cells_out, uint64_t *n_pairs_out)
+                uint32_t n_haps, uint32_t *slot_first, uint32_t *pair_first, std::vector<Bin> &bins, uint64_t *cells_out, uint64_t *n_pairs_out,
+                bool ride_along)
 {
     // pass 1: validate, count the pairs of every class, note each class's longest read and haplotype
     uint64_t count[kClasses] = {0};
@@ -303,7 +329,7 @@ int bin_regions(const phmm_region *regions, uint32_t n_regions, const uint32_t *
             cursor[k] += rg.n_haps;
         }
     }
-    merge_small_bins(bins, queue_per_class);
+    if (ride_along) merge_small_bins(bins, queue_per_class);
     *cells_out = cells;
     *n_pairs_out = n_pairs;
     return PHMM_OK;

@@ -43,17 +43,20 @@ constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kerne
 
 
 // Test and tuning hooks are environment variables named PHMM_*, looked up where they apply so that a test can flip them between
-// calls.  A production process has none: an entry point on the latency-critical path (phmm_stage_submit, phmm_compute) opens a
-// HookScope, which scans the environment ONCE for the prefix, and every phmm_hook() inside it is then a thread-local flag test
-// instead of a getenv (a dozen of them cost a region-sized submission 3-5 us).  Outside a scope phmm_hook is plain getenv.
+// calls -- and ALL of them are dead unless PHMM_ENABLE_TEST_HOOKS=1 is set as well: they change launch geometry, force slower kernel
+// shapes or lift safety checks (PHMM_MULTI_ALLOW_SHARED_DEVICE), and a production process that happens to inherit one must not run a
+// shape three times slower for it.  An entry point on the latency-critical path (phmm_stage_submit, phmm_compute) opens a HookScope,
+// which reads the master switch ONCE, and every phmm_hook() inside it is then a thread-local flag test instead of a getenv (a dozen
+// of them cost a region-sized submission 3-5 us).  Outside a scope phmm_hook looks the switch up itself.
+// (Not hooks, read directly: PHMM_PHASE_TIMING -- diagnostics on stderr -- and PHMM_STAGE_BLOCKING_SYNC -- an operating choice.)
 namespace phmm_detail
 {
-extern thread_local int t_hooks;  // -1: no scope open (look up); 0: the environment has no PHMM_* variable; 1: it has
-bool any_phmm_variable();
+extern thread_local int t_hooks;  // -1: no scope open (look up); 0: hooks are off; 1: PHMM_ENABLE_TEST_HOOKS is set
+bool test_hooks_enabled();
 struct HookScope
 {
     int saved;
-    HookScope() : saved(t_hooks) { if (t_hooks < 0) t_hooks = any_phmm_variable() ? 1 : 0; }
+    HookScope() : saved(t_hooks) { if (t_hooks < 0) t_hooks = test_hooks_enabled() ? 1 : 0; }
     ~HookScope() { t_hooks = saved; }
     HookScope(const HookScope &) = delete;
     HookScope &operator=(const HookScope &) = delete;
@@ -79,6 +82,10 @@ static inline uint32_t class_of(uint32_t R, uint32_t H)
 // launch per class would add more latency than the divergence costs.
 static inline int queue_of_bin(int bin_id, bool queue_per_class) { return bin_id >= 17 ? bin_id - 16 : queue_per_class ? 4 + bin_id : 0; }
 bool queue_per_class_for(uint64_t n_pairs);  // n_pairs > kQueuePerClassMinPairs, or PHMM_FORCE_QUEUE_PER_CLASS (tests)
+// Ragged launches (pairhmm_kernels_ragged.hip): the single-pass classes of a batch in the Rovaca case (one gap-continuation quality,
+// deletion == insertion gap-opens: every batch the adapter makes) share launches, so its bins are left one per class -- no ride-along,
+// no padding rows.  PHMM_NO_RAGGED: the A/B hook (one launch per bin, small bins ride along, as until round 3).
+bool ragged_launches_for(bool uniform_gcp);
 
 // Host loops over the pairs of a BIG batch (binning, packing, the final log10) are split over a few threads; a region-sized call
 // never gets here.  Two ways to get the threads: a HostPool the calling thread has made current (the chunked one-shot call keeps
@@ -106,6 +113,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(mu_);
             stop_ = true;
+            stop_atomic_.store(true, std::memory_order_relaxed);
             ++generation_;
         }
         cv_.notify_all();
@@ -114,6 +122,10 @@ public:
     HostPool(const HostPool &) = delete;
     HostPool &operator=(const HostPool &) = delete;
     unsigned helpers() const { return (unsigned)threads_.size(); }
+    // While hot the helpers never go to sleep between jobs: the chunk pipeline of a one-shot call hands them a dozen short jobs per
+    // chunk with serial stretches in between, and a helper that has to be woken through the condition variable (tens of microseconds on
+    // a busy box) arrives when the job is half done.  The owner switches it on for the duration of a call (8-10 ms), never for longer.
+    void set_hot(bool on) { hot_.store(on, std::memory_order_release); }
     template <typename F>
     void run(unsigned parts, F &&fn)  // fn(part index)
     {
@@ -147,6 +159,40 @@ public:
         fn_ = nullptr;
     }
 
+    // The same job handed to the helpers ALONE, without the caller taking part or waiting: begin() returns at once, the helpers take
+    // the parts in ascending order, end() waits for the last one.  (The chunk pipeline's prepare workers: the caller enqueues chunk k on
+    // the device while the helpers pack and bin chunks k + 1, k + 2, ...)  Needs at least one helper.
+    void begin(unsigned parts, std::function<void(unsigned)> fn)
+    {
+        run_mu_.lock();  // one job at a time; released by end()
+        async_fn_ = std::move(fn);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            while (in_job_ != 0) {
+                lk.unlock();
+                std::this_thread::yield();
+                lk.lock();
+            }
+            fn_ = &async_fn_;
+            parts_ = parts;
+            next_.store(0, std::memory_order_relaxed);
+            done_.store(0, std::memory_order_relaxed);
+            ++generation_;
+            gen_atomic_.store(generation_, std::memory_order_release);
+        }
+        cv_.notify_all();
+    }
+    void end()
+    {
+        for (unsigned spins = 0; done_.load(std::memory_order_acquire) != parts_; ++spins)
+            if (spins > 2000) std::this_thread::yield();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = nullptr;
+        }
+        run_mu_.unlock();
+    }
+
 private:
     void work(std::function<void(unsigned)> &f, unsigned parts)
     {
@@ -169,7 +215,11 @@ private:
                     fresh = true;
                     break;
                 }
-                if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+                if ((spins & 63u) == 63u && !hot_.load(std::memory_order_acquire) &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100))
+                    break;
+                if (stop_atomic_.load(std::memory_order_relaxed)) break;
+                __builtin_ia32_pause();
             }
             std::function<void(unsigned)> *f = nullptr;
             unsigned parts = 0;
@@ -193,13 +243,16 @@ private:
     std::condition_variable cv_;
     std::vector<std::thread> threads_;
     std::function<void(unsigned)> *fn_ = nullptr;
+    std::function<void(unsigned)> async_fn_;
     unsigned parts_ = 0, in_job_ = 0;
     std::atomic<unsigned> next_{0}, done_{0};
     uint64_t generation_ = 0;
     std::atomic<uint64_t> gen_atomic_{0};
+    std::atomic<bool> hot_{false}, stop_atomic_{false};
     bool stop_ = false;
 };
 extern thread_local HostPool *t_pool;  // the pool parallel_ranges uses on this thread, or null: spawn
+extern thread_local bool t_serial;     // this thread is itself one of several workers: its loops stay on it (no helpers, no spawning)
 struct PoolScope
 {
     HostPool *saved;
@@ -211,6 +264,10 @@ struct PoolScope
 template <typename F>
 static void parallel_ranges(uint64_t n, unsigned n_threads, F &&fn)  // fn(lo, hi, thread index)
 {
+    if (phmm_detail::t_serial) {
+        for (unsigned t = 0; t < n_threads; ++t) fn(n * t / n_threads, n * (t + 1) / n_threads, t);
+        return;
+    }
     if (phmm_detail::HostPool *pool = phmm_detail::t_pool) {
         pool->run(n_threads, [&](unsigned t) { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
         return;
@@ -250,8 +307,10 @@ struct BinScratch  // host scratch of the pair binning, kept between calls by it
 // hap_bias are subtracted from the indices of a pair list that counts from the start of the caller's tables while b's tables
 // are windows of them.  Writes pr[p], ph[p] (the pair list as the kernels index it) and order[0 .. n_pairs), appends the
 // launches to `bins`.  PHMM_E_INVALID (with the message set) when a pair indexes outside the tables.
+// ride_along: small single-pass bins are handed to the next bin up (merge_small_bins, pairhmm_binning.cpp) -- the way a batch of mixed
+// lengths keeps its launch count down when its classes cannot share a ragged launch (ragged_launches_for below).
 int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_bias, uint32_t hap_bias, uint32_t *pr, uint32_t *ph,
-              uint32_t *order, BinScratch &scratch, std::vector<Bin> &bins, uint64_t *cells);
+              uint32_t *order, BinScratch &scratch, std::vector<Bin> &bins, uint64_t *cells, bool ride_along = true);
 
 // Region form: every region is the cross product of a run of reads with a run of haplotypes, so the placement is decided per
 // READ (O(reads) host work; the pair list itself is spelled out on the device): order = (class, region, read, hap), and
@@ -259,6 +318,7 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
 // count region by region, [read][hap] inside one).  Regions must list their reads in ascending, non-overlapping runs;
 // haplotypes may be shared.  A region with a haplotype above the single-pass budget sends all its pairs to the striped kernel.
 int bin_regions(const phmm_region *regions, uint32_t n_regions, const uint32_t *read_len, uint32_t n_reads, const uint32_t *hap_len,
-                uint32_t n_haps, uint32_t *slot_first, uint32_t *pair_first, std::vector<Bin> &bins, uint64_t *cells, uint64_t *n_pairs);
+                uint32_t n_haps, uint32_t *slot_first, uint32_t *pair_first, std::vector<Bin> &bins, uint64_t *cells, uint64_t *n_pairs,
+                bool ride_along = true);
 }  // namespace phmm_detail
 #endif

@@ -82,7 +82,7 @@ int phmm_create(int device_id, void *stream, phmm_context **out)
     phmm_context *c = new (std::nothrow) phmm_context();
     if (!c) return fail(PHMM_E_NOMEM, "phmm_create: out of host memory");
     c->device = device_id;
-    if (const char *e = getenv("PHMM_SIDE_STREAMS")) c->n_side = std::max(0, std::min((int)phmm_context::kSideStreams, atoi(e)));
+    if (const char *e = phmm_hook("PHMM_SIDE_STREAMS")) c->n_side = std::max(0, std::min((int)phmm_context::kSideStreams, atoi(e)));
     if (stream) {
         c->stream = static_cast<hipStream_t>(stream);
     }
@@ -177,6 +177,7 @@ void phmm_destroy(phmm_context *c)
     }
     delete c->pack_pool;
     delete c->fin_pool;
+    delete c->prep_pool;
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -200,7 +201,11 @@ void phmm_release(phmm_context *c, phmm_resident *rb)
 }
 
 // (PhaseClock / PHASE, UploadOpts: pairhmm_engine.h)
-int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt)
+// A batch reaches the device in two halves.  upload_prepare is host work only -- validate, pack every input into the resident's ONE
+// pinned staging buffer, bin the pairs -- and touches nothing of the context but the device number, so the chunk pipeline of a big
+// one-shot call runs it for several chunks at once on worker threads (pairhmm_chunked.cpp).  upload_enqueue is the HIP side: one copy,
+// the views into the blob, the device buffers, the set-up launch; the pipeline keeps it on one thread, in chunk order.
+int upload_prepare(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt, phmm_detail::BinScratch &bin_scratch)
 {
     if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
         return fail(PHMM_E_INVALID, "phmm_upload: pair_read and pair_hap must both be given or both be NULL");
@@ -281,7 +286,6 @@ int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const U
     uint64_t slots = 0;
     for (uint32_t h = 0; h < b->n_haps; ++h) slots += phmm::planes_words(b->hap_len[h]);
     if (slots * phmm::kPlanes > 0xFFFFFFF0ull) return fail(PHMM_E_INVALID, "phmm_upload: haplotype table too large");
-    hipStream_t st = opt.stream ? opt.stream : c->stream;
     if (!opt.caller_synchronised)
         HIP_TRY(hipStreamSynchronize(c->stream));  // the previous pass of this resident batch no longer reads the stage or the blob
     size_t total = 0;
@@ -301,10 +305,11 @@ int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const U
     const size_t o_order = reserve(n_pairs * sizeof(uint32_t));
     const size_t o_poff = reserve(b->n_haps * sizeof(uint32_t)), o_owner = reserve(slots * sizeof(uint32_t));
     HIP_TRY(rb->stage.ensure(total));
-    HIP_TRY(rb->blob.alloc(total));
     uint8_t *stage = static_cast<uint8_t *>(rb->stage.p);
     auto copy = [](void *dst, const void *src, size_t bytes) {  // big tables of a big batch: a few threads share the copy
-        if (bytes < (size_t(1) << 20)) {
+        // (with the chunk pipeline's helper pool current, handing out parts costs microseconds: a chunk's tables of a few hundred KB each
+        // are split too -- they were 0.25 ms of serial memcpy per chunk of 118 000 pairs)
+        if (bytes < (phmm_detail::t_pool ? (size_t(1) << 17) : (size_t(1) << 20))) {
             memcpy(dst, src, bytes);
             return;
         }
@@ -349,13 +354,46 @@ int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const U
     // ---- pair list (materialise the cross product) and length binning: pairhmm_binning.cpp ----
     uint64_t cells = 0;
     {
-        const int rc = phmm_detail::bin_pairs(b, cross, n_pairs, opt.read_bias, opt.hap_bias, pr, ph, order, c->bin_scratch, rb->bins, &cells);
+        rb->ragged = ragged_launches_for(ug);  // the classes share launches: no need for small ones to ride along at more rows per lane
+        const int rc = phmm_detail::bin_pairs(b, cross, n_pairs, opt.read_bias, opt.hap_bias, pr, ph, order, bin_scratch, rb->bins, &cells,
+                                              !rb->ragged);
         if (rc != PHMM_OK) return rc;
         merge_striped_bins_of_one_shape(rb->bins);
     }
     rb->cells = cells;
     PHASE(2);
 
+    // what upload_enqueue needs of the layout
+    UploadPlan &pl = rb->plan;
+    pl.total = total;
+    pl.read_bytes = read_bytes;
+    pl.hap_bytes = hap_bytes;
+    pl.slots = slots;
+    pl.o_bases = o_bases, pl.o_qual = o_qual, pl.o_mapq = o_mapq, pl.o_ins = o_ins, pl.o_del = o_del, pl.o_gcp = o_gcp;
+    pl.o_roff = o_roff, pl.o_rlen = o_rlen, pl.o_hap = o_hap, pl.o_hoff = o_hoff, pl.o_hlen = o_hlen;
+    pl.o_pr = o_pr, pl.o_ph = o_ph, pl.o_order = o_order, pl.o_poff = o_poff, pl.o_owner = o_owner;
+    pl.has_prep = prep != nullptr;
+    pl.slim = slim;
+    pl.gcp0 = gcp0;
+    if (prep) pl.prep = *prep;  // (read_mapq was packed above: only the scalars are read again)
+    return PHMM_OK;
+}
+
+int upload_enqueue(phmm_context *c, phmm_resident *rb, const UploadOpts &opt)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    const UploadPlan &pl = rb->plan;
+    const size_t total = pl.total;
+    const uint64_t read_bytes = pl.read_bytes, hap_bytes = pl.hap_bytes, slots = pl.slots, n_pairs = rb->n_pairs;
+    const size_t o_bases = pl.o_bases, o_qual = pl.o_qual, o_mapq = pl.o_mapq, o_ins = pl.o_ins, o_del = pl.o_del, o_gcp = pl.o_gcp,
+                 o_roff = pl.o_roff, o_rlen = pl.o_rlen, o_hap = pl.o_hap, o_hoff = pl.o_hoff, o_hlen = pl.o_hlen, o_pr = pl.o_pr,
+                 o_ph = pl.o_ph, o_order = pl.o_order, o_poff = pl.o_poff, o_owner = pl.o_owner;
+    const bool slim = pl.slim;
+    const uint8_t gcp0 = pl.gcp0;
+    const phmm_read_prep *prep = pl.has_prep ? &pl.prep : nullptr;
+    const uint32_t n_reads = rb->n_reads, n_haps = rb->n_haps;
+    hipStream_t st = opt.stream ? opt.stream : c->stream;
+    HIP_TRY(rb->blob.alloc(total));
     // ---- upload ----
     if (opt.setup_stream && opt.setup_stream != st) {
         // The chunked call's synchronous form (PHMM_CHUNK_SYNC_UPLOAD; the default until the process asked for 16 hardware queues): the
@@ -373,16 +411,16 @@ int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const U
     uint8_t *base = rb->blob.p;
     rb->read_bases = {base + o_bases, (size_t)read_bytes};
     rb->read_qual = {base + o_qual, (size_t)read_bytes};
-    rb->read_mapq = {base + o_mapq, prep ? (size_t)b->n_reads : 0};
-    rb->read_off = {reinterpret_cast<uint32_t *>(base + o_roff), b->n_reads};
-    rb->read_len = {reinterpret_cast<uint32_t *>(base + o_rlen), b->n_reads};
+    rb->read_mapq = {base + o_mapq, prep ? (size_t)n_reads : 0};
+    rb->read_off = {reinterpret_cast<uint32_t *>(base + o_roff), n_reads};
+    rb->read_len = {reinterpret_cast<uint32_t *>(base + o_rlen), n_reads};
     rb->hap_bases = {base + o_hap, (size_t)hap_bytes};
-    rb->hap_off = {reinterpret_cast<uint32_t *>(base + o_hoff), b->n_haps};
-    rb->hap_len = {reinterpret_cast<uint32_t *>(base + o_hlen), b->n_haps};
+    rb->hap_off = {reinterpret_cast<uint32_t *>(base + o_hoff), n_haps};
+    rb->hap_len = {reinterpret_cast<uint32_t *>(base + o_hlen), n_haps};
     rb->pair_read = {reinterpret_cast<uint32_t *>(base + o_pr), (size_t)n_pairs};
     rb->pair_hap = {reinterpret_cast<uint32_t *>(base + o_ph), (size_t)n_pairs};
     rb->order = {reinterpret_cast<uint32_t *>(base + o_order), (size_t)n_pairs};
-    rb->plane_off = {reinterpret_cast<uint32_t *>(base + o_poff), b->n_haps};
+    rb->plane_off = {reinterpret_cast<uint32_t *>(base + o_poff), n_haps};
     rb->word_owner = {reinterpret_cast<uint32_t *>(base + o_owner), (size_t)slots};
     if (prep) {
         HIP_TRY(rb->prep_gop.alloc(read_bytes));
@@ -428,7 +466,7 @@ int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const U
         sa.read_off = rb->read_off.p;
         sa.read_len = rb->read_len.p;
         sa.read_mapq = rb->read_mapq.p;
-        sa.n_prep_reads = prep ? b->n_reads : 0;
+        sa.n_prep_reads = prep ? n_reads : 0;
         sa.min_q = prep ? prep->min_quality_threshold : 0;
         sa.pcr_model = prep ? prep->pcr_model : 0;
         sa.gap_open = prep ? prep->gap_open : 0;
@@ -439,6 +477,12 @@ int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const U
     }
     PHASE(3);
     return PHMM_OK;
+}
+
+int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt)
+{
+    const int rc = upload_prepare(c, b, rb, opt, c->bin_scratch);
+    return rc != PHMM_OK ? rc : upload_enqueue(c, rb, opt);
 }
 
 // ---- CPU backend (phmm_create_cpu): the same entry points, computed on the host by pairhmm_cpu.cpp ----
@@ -587,11 +631,6 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
 {
     if (rb->n_pairs && !rb->queue_is_empty) HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, kQueues * sizeof(uint32_t), c->stream));
     rb->queue_is_empty = false;
-    const bool fan_out = rb->bins.size() > 1;
-    if (fan_out) {
-        HIP_TRY(hipEventRecord(c->fork, c->stream));
-        for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
-    }
     // striped launches run side by side on different streams: each gets its own slice of the carry buffer, sized up front
     struct StripedPlan
     {
@@ -612,8 +651,57 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         carry_total += (phmm::team_carry_values(pl.teams, pl.sh.waves, bin.max_hap_len + 1, pl.sh.lanes) + 63) & ~size_t(63);
     }
     HIP_TRY(rb->carry32.alloc(carry_total));
+    // The launches of the pass.  A striped bin is one launch.  Single-pass bins are one launch each too -- unless the batch takes ragged
+    // launches (the Rovaca case; pairhmm_kernels_ragged.hip): then a run of single-pass bins is cut into the K ranges that share a
+    // kernel and every range with more than one bin is ONE launch whose workgroups pick their class's K, longest rows first.
+    struct FpLaunch
+    {
+        size_t first, n;  // bins [first, first + n)
+        int lanes;        // single-pass launches: lanes per pair (16 / 64); 0: not decided here (striped, or the per-bin rule)
+    };
+    uint32_t wide_max = kWideMaxPairs;
+    if (const char *f = phmm_hook("PHMM_WIDE_MAX_PAIRS")) wide_max = (uint32_t)std::max(0, atoi(f));  // tuning
+    int forced_lanes = 0;
+    if (const char *f = phmm_hook("PHMM_FORCE_LANES")) {  // tests
+        const int l = atoi(f);
+        if (l == 16 || l == 64) forced_lanes = l;
+    }
+    uint32_t xcd_min = kXcdLocalMinPairs;
+    if (const char *f = phmm_hook("PHMM_XCD_LOCAL_MIN_PAIRS")) xcd_min = (uint32_t)std::max(1, atoi(f));  // tests: small launches too
+    const bool xcd_local = !phmm_hook("PHMM_NO_XCD_LOCAL_ORDER");
+    auto wide_rows = [](const Bin &b) { return (int)((b.max_read_len + 63) / 64); };  // rows per lane at one pair per wave
+    std::vector<FpLaunch> launches;
+    for (size_t i = 0; i < rb->bins.size();) {
+        if (!(rb->ragged && rb->bins[i].rows_per_lane > 0)) {
+            launches.push_back(FpLaunch{i, 1, 0});
+            ++i;
+            continue;
+        }
+        size_t j = i;
+        uint64_t total = 0;
+        for (; j < rb->bins.size() && rb->bins[j].rows_per_lane > 0; ++j) total += rb->bins[j].count;
+        // few pairs in the whole run: one pair per wave (see the one-launch-per-bin rule below)
+        const int lanes = forced_lanes ? forced_lanes : total <= wide_max ? 64 : 16;
+        for (size_t k = i; k < j;) {
+            const int range = phmm::ragged_range_of(lanes == 64 ? wide_rows(rb->bins[k]) : rb->bins[k].rows_per_lane, lanes, rb->uniform_gop);
+            size_t e = k + 1;
+            while (e < j && e - k < (size_t)phmm::kRaggedMaxSegs &&
+                   phmm::ragged_range_of(lanes == 64 ? wide_rows(rb->bins[e]) : rb->bins[e].rows_per_lane, lanes, rb->uniform_gop) == range)
+                ++e;
+            launches.push_back(FpLaunch{k, e - k, lanes});
+            k = e;
+        }
+        i = j;
+    }
+    rb->last_fp32_launches = (uint32_t)launches.size();
+    const bool fan_out = launches.size() > 1;
+    if (fan_out) {
+        HIP_TRY(hipEventRecord(c->fork, c->stream));
+        for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
+    }
     int nth = 0;
-    for (size_t i = 0; i < rb->bins.size(); ++i) {
+    for (const FpLaunch &L : launches) {
+        const size_t i = L.first;
         const Bin &bin = rb->bins[i];
         const int lane = fan_out ? nth++ % (c->n_side + 1) : 0;
         hipStream_t stream = lane == 0 ? c->stream : c->side[lane - 1];
@@ -640,24 +728,44 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         // underflowed pairs go to the queue of the bin's size range (queue 0 starts at 0, a striped range at its own first)
         a.rescue_list = rb->rescue_list.p + (bin.queue == 0 ? 0 : bin.first);
         a.rescue_count = rb->rescue_count.p + bin.queue;
-        if (bin.rows_per_lane > 0) {
+        if (bin.rows_per_lane > 0 && L.n > 1) {
+            // a ragged launch over the classes of bins [first, first + n): longest rows first
+            phmm::RaggedArgs m{};
+            uint32_t wg = 0, lds_words = 0;
+            uint64_t total = 0;
+            const uint32_t per_wg = L.lanes == 64 ? 1u : (uint32_t)phmm::kBlockThreads / 16u;
+            for (size_t q = L.n; q-- > 0;) {
+                const Bin &sb = rb->bins[L.first + q];
+                phmm::RaggedSeg &sg = m.seg[m.n_seg++];
+                sg.wg_first = wg;
+                sg.pos_first = sb.first;
+                sg.count = sb.count;
+                sg.rows = (uint32_t)(L.lanes == 64 ? wide_rows(sb) : sb.rows_per_lane);
+                sg.queue = (uint32_t)sb.queue;
+                sg.list_base = sb.queue == 0 ? 0u : sb.first;
+                wg += (sb.count + per_wg - 1) / per_wg;
+                lds_words = std::max(lds_words, sb.lds_words_per_group);
+                total += sb.count;
+            }
+            m.n_wg = wg;
+            a.order = rb->order.p;
+            a.n_pairs = 0;
+            a.lds_words_per_group = lds_words;
+            a.rescue_list = rb->rescue_list.p;
+            a.rescue_count = rb->rescue_count.p;
+            if (L.lanes == 16 && total >= xcd_min && xcd_local) a.xcd_run_log2 = 6;
+            HIP_TRY(phmm::launch_systolic_ragged_f32(L.lanes, rb->uniform_gop, a, m, stream));
+        }
+        else if (bin.rows_per_lane > 0) {
             // Few pairs: one pair per wave.  Four per wave would occupy count / 4 of the chip's 1024 SIMDs with one slow wave
             // each; 64 lanes per pair makes the sweep of a pair about half as long (a quarter of the rows per lane, 48 more
             // steps) at 1.8x the instructions, which is free while SIMDs idle.  Measured: a 432-pair region 85 -> 46 us, 1728
             // pairs 86 -> 68 us, no gain from 4000 pairs on, and a loss when several submissions share the chip, hence the
             // low threshold.
-            uint32_t wide_max = kWideMaxPairs;
-            if (const char *f = phmm_hook("PHMM_WIDE_MAX_PAIRS")) wide_max = (uint32_t)std::max(0, atoi(f));  // tuning
-            int lanes = bin.count <= wide_max ? 64 : 16;
-            if (const char *f = phmm_hook("PHMM_FORCE_LANES")) {  // tests
-                const int l = atoi(f);
-                if (l == 16 || l == 64) lanes = l;
-            }
-            const int k = lanes == 64 ? (int)((bin.max_read_len + 63) / 64) : bin.rows_per_lane;
+            const int lanes = L.lanes ? L.lanes : forced_lanes ? forced_lanes : bin.count <= wide_max ? 64 : 16;
+            const int k = lanes == 64 ? wide_rows(bin) : bin.rows_per_lane;
             // big four-pairs-per-wave launches: runs of 64 workgroups (1 024 pairs, a region or so) per XCD, see KernelArgs
-            uint32_t xcd_min = kXcdLocalMinPairs;
-            if (const char *f = phmm_hook("PHMM_XCD_LOCAL_MIN_PAIRS")) xcd_min = (uint32_t)std::max(1, atoi(f));  // tests: small launches too
-            if (lanes == 16 && bin.count >= xcd_min && !phmm_hook("PHMM_NO_XCD_LOCAL_ORDER")) a.xcd_run_log2 = 6;
+            if (lanes == 16 && bin.count >= xcd_min && xcd_local) a.xcd_run_log2 = 6;
             HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream, rb->uniform_gop));
             a.xcd_run_log2 = 0;
         }
@@ -695,8 +803,6 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb)
         uint32_t base = 0, cap = 0, max_read = 0, max_hap = 0;
         int rows = phmm::kStripedRowsF64Min;
         TeamShape sh{16, 1};
-        uint32_t teams = 0;
-        size_t carry_at = 0;
     } q[kQueues];
     for (const Bin &bin : rb->bins) {
         QueuePlan &p = q[bin.queue];
@@ -706,11 +812,9 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb)
         p.max_hap = std::max(p.max_hap, bin.max_hap_len);
     }
     size_t carry_total = 0;
-    int n_active = 0;
     for (int qi = 0; qi < kQueues; ++qi) {
         QueuePlan &p = q[qi];
         if (p.cap == 0) continue;
-        ++n_active;
         // Rows per lane: more rows amortise the per-step work of a stripe better (measured rate per computed cell 1.00 :
         // 1.12 : 1.21 for 4 : 5 : 6), but the last stripe of a read is padded to a whole stripe -- 150-base reads are
         // 3 x 64, 2 x 80 or 2 x 96 rows.  Take the value with the least estimated time over the queue's length bins.
@@ -732,21 +836,53 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb)
             }
         }
         // (teams of several waves run the band kernel at kBandRows rows per lane whatever p.rows says: launch_striped_f64)
-        const uint32_t per_wave = 64u / (uint32_t)p.sh.lanes;
-        p.teams = std::min<uint32_t>((p.cap + per_wave - 1) / per_wave, kRescueMaxTeams / p.sh.waves);
-        p.carry_at = carry_total;
-        carry_total += (phmm::team_carry_values(p.teams, p.sh.waves, p.max_hap + 1, p.sh.lanes) + 63) & ~size_t(63);
+    }
+    // Queues whose re-run takes the same kernel (rows per lane, team shape) share ONE launch: its teams stride over the queues one after
+    // the other, four pairs of one queue at a time (KernelArgs::n_rescue_queues).  A batch of mixed lengths has a queue per length class
+    // -- thirteen for reads of 50-250 bases -- and nearly all of them are empty nearly always; thirteen launches cost a pass 0.3 ms of a
+    // mostly idle chip (rocprofv3 time line of config 3's one-shot call, round 4), at every chunk boundary.  PHMM_NO_RESCUE_MERGE: A/B hook.
+    struct RescueLaunch
+    {
+        int rows;
+        TeamShape sh;
+        std::vector<int> queues;
+        uint32_t cap = 0, max_hap = 0, teams = 0;
+        size_t carry_at = 0;
+    };
+    std::vector<RescueLaunch> launches;
+    const bool merge = !phmm_hook("PHMM_NO_RESCUE_MERGE");
+    for (int qi = 0; qi < kQueues; ++qi) {
+        const QueuePlan &p = q[qi];
+        if (p.cap == 0) continue;
+        RescueLaunch *into = nullptr;
+        if (merge)
+            for (RescueLaunch &L : launches)
+                if (L.rows == p.rows && L.sh.lanes == p.sh.lanes && L.sh.waves == p.sh.waves &&
+                    L.queues.size() < (size_t)phmm::kMaxRescueQueuesPerLaunch)
+                    into = &L;
+        if (!into) {
+            launches.push_back(RescueLaunch{p.rows, p.sh, {}, 0, 0, 0, 0});
+            into = &launches.back();
+        }
+        into->queues.push_back(qi);
+        into->cap += p.cap;
+        into->max_hap = std::max(into->max_hap, p.max_hap);
+    }
+    carry_total = 0;
+    for (RescueLaunch &L : launches) {
+        const uint32_t per_wave = 64u / (uint32_t)L.sh.lanes;
+        L.teams = std::min<uint32_t>((L.cap + per_wave - 1) / per_wave, kRescueMaxTeams / L.sh.waves);
+        L.carry_at = carry_total;
+        carry_total += (phmm::team_carry_values(L.teams, L.sh.waves, L.max_hap + 1, L.sh.lanes) + 63) & ~size_t(63);
     }
     HIP_TRY(rb->carry64.alloc(carry_total));
-    const bool fan_out = n_active > 1;
+    const bool fan_out = launches.size() > 1;
     if (fan_out) {
         HIP_TRY(hipEventRecord(c->fork, c->stream));
         for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
     }
     int nth = 0;
-    for (int qi = 0; qi < kQueues; ++qi) {
-        const QueuePlan &p = q[qi];
-        if (p.cap == 0) continue;
+    for (const RescueLaunch &L : launches) {
         const int lane = fan_out ? nth++ % (c->n_side + 1) : 0;
         hipStream_t st = lane == 0 ? c->stream : c->side[lane - 1];
         phmm::KernelArgs a{};
@@ -762,16 +898,28 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb)
         a.plane_off = rb->plane_off.p;
         a.pair_read = rb->pair_read.p;
         a.pair_hap = rb->pair_hap.p;
-        a.order = rb->rescue_list.p + p.base;
         a.n_pairs = 0;
-        a.n_pairs_dev = rb->rescue_count.p + qi;
-        a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(p.max_hap);
+        if (L.queues.size() == 1) {
+            const int qi = L.queues[0];
+            a.order = rb->rescue_list.p + q[qi].base;
+            a.n_pairs_dev = rb->rescue_count.p + qi;
+        }
+        else {
+            a.order = rb->rescue_list.p;
+            a.rescue_count = rb->rescue_count.p;  // (read, not written, by the fp64 launches)
+            a.n_rescue_queues = (uint32_t)L.queues.size();
+            for (size_t i = 0; i < L.queues.size(); ++i) {
+                a.rescue_queue[i] = (uint32_t)L.queues[i];
+                a.rescue_base[i] = q[L.queues[i]].base;
+            }
+        }
+        a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(L.max_hap);
         a.no_early_exit = phmm_hook("PHMM_NO_EARLY_EXIT") ? 1u : 0u;  // tests
         a.ph2pr = c->ph2pr_f64.p;
         a.mm_table = c->mm_f64.p;
         a.out_raw = rb->out64_host ? static_cast<void *>(rb->out64_host) : static_cast<void *>(rb->raw64.p);
-        HIP_TRY(phmm::launch_striped_f64(p.rows, rb->uniform_gcp, p.sh.waves, p.sh.lanes, a, rb->carry64.p + p.carry_at,
-                                         p.max_hap + 1, p.teams, st));
+        HIP_TRY(phmm::launch_striped_f64(L.rows, rb->uniform_gcp, L.sh.waves, L.sh.lanes, a, rb->carry64.p + L.carry_at, L.max_hap + 1,
+                                         L.teams, st));
     }
     if (fan_out) {
         for (int i = 0; i < c->n_side; ++i) {
@@ -902,7 +1050,7 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
         stats->cells = rb->cells;
         stats->n_rescued = rb->last_rescued;
         stats->kernel_ms = rb->last_kernel_ms;
-        stats->n_launches = (uint32_t)rb->bins.size();
+        stats->n_launches = rb->last_fp32_launches ? rb->last_fp32_launches : (uint32_t)rb->bins.size();
         stats->max_rows_per_lane = rb->bins.empty() ? 0 : (uint32_t)rb->bins.back().rows_per_lane;
     }
     return PHMM_OK;

@@ -246,7 +246,7 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         rb->last_rescued = (uint32_t)n_resc.load();
         total.cells += rb->cells;
         total.n_rescued += rb->last_rescued;
-        total.n_launches += (uint32_t)rb->bins.size();
+        total.n_launches += rb->last_fp32_launches ? rb->last_fp32_launches : (uint32_t)rb->bins.size();
         if (!rb->bins.empty()) total.max_rows_per_lane = std::max<uint32_t>(total.max_rows_per_lane, (uint32_t)rb->bins.back().rows_per_lane);
         if (trace) fprintf(stderr, "phmm chunk %zu: results on the host at %.0f us, converted at %.0f us\n", k, t_ready, now_us());
         return PHMM_OK;
@@ -308,50 +308,179 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         }
     } joiner{collector, mu, cv, producer_failed};
 
-    phmm_detail::PoolScope pool(c->pack_pool);
-    std::vector<uint32_t> roff, hoff;
-    for (size_t k = 0; k < n_chunks; ++k) {
+    // ---- the producer side: prepare workers + the calling thread as enqueuer ----
+    // Packing and binning a chunk is host work only (upload_prepare) and takes about as long as the device needs to sweep it: 0.65-0.9 ms
+    // for 118 000 pairs of mixed lengths against 0.93 ms (round 4's time line of config 3: the producer finished its last chunk at
+    // 10-11 ms of a pass that takes the device 7.9 ms).  So the chunks are prepared by a few worker threads, several at a time and each
+    // on one thread (no nested helpers), into the slots' pinned staging buffers; the calling thread only enqueues them, in order -- the
+    // copy, the set-up launch, the sweeps: 0.1 ms per chunk -- and is never the bottleneck.  PHMM_CHUNK_PREP_THREADS=0: the calling
+    // thread prepares every chunk itself (the form until round 3; also what a process out of threads gets).
+    unsigned n_prep = 3;
+    if (const char *e = phmm_hook("PHMM_CHUNK_PREP_THREADS")) n_prep = (unsigned)std::max(0, std::min(8, atoi(e)));
+    if (n_prep && (!c->prep_pool || c->prep_pool->helpers() == 0)) {
+        delete c->prep_pool;
+        c->prep_pool = new phmm_detail::HostPool(n_prep);
+        if (c->prep_pool->helpers() == 0) n_prep = 0;
+    }
+    struct ChunkInput  // the chunk as a batch of its own; the vectors live as long as the slot holds the chunk
+    {
+        std::vector<uint32_t> roff, hoff;
+        phmm_read_prep prep_k{};
+        phmm_batch s{};
+        UploadOpts opt;
+        PhaseClock clock;
+        double t_a = 0.0, t_b = 0.0;
+    };
+    std::vector<ChunkInput> input(S);
+    std::vector<int> prepared(n_chunks, -1);  // -1: not yet; else the status of upload_prepare (guarded by mu)
+    std::vector<std::string> prepared_msg(n_chunks);
+    const bool tracing = trace;
+    auto prepare = [&](size_t k, phmm_detail::BinScratch &scratch) -> int {
         const ChunkWindow &w = plan[k];
         const int slot = (int)(k % S);
-        if (k >= (size_t)S) {  // the slot held chunk k - S: its results must have left it
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return collected + S > k; });
-            if (collector_rc != PHMM_OK) break;
-        }
-        const double t_a = trace ? now_us() : 0.0;
+        ChunkInput &in = input[slot];
         phmm_resident *rb = c->chunk_slot[slot];
+        in.t_a = tracing ? now_us() : 0.0;
         // the chunk as a batch of its own: windows of the tables, offsets rebased to the windows, pair indices biased
-        phmm_batch s = *b;
+        phmm_batch &s = in.s;
+        s = *b;
         s.n_reads = w.r1 - w.r0;
         s.n_haps = w.h1 - w.h0;
         s.n_pairs = w.p1 - w.p0;
-        roff.resize(s.n_reads);
-        for (uint32_t r = 0; r < s.n_reads; ++r) roff[r] = (uint32_t)(b->read_off[w.r0 + r] - w.rb0);
-        hoff.resize(s.n_haps);
-        for (uint32_t h = 0; h < s.n_haps; ++h) hoff[h] = (uint32_t)(b->hap_off[w.h0 + h] - w.hb0);
+        in.roff.resize(s.n_reads);
+        for (uint32_t r = 0; r < s.n_reads; ++r) in.roff[r] = (uint32_t)(b->read_off[w.r0 + r] - w.rb0);
+        in.hoff.resize(s.n_haps);
+        for (uint32_t h = 0; h < s.n_haps; ++h) in.hoff[h] = (uint32_t)(b->hap_off[w.h0 + h] - w.hb0);
         s.read_bases = b->read_bases + w.rb0;
         s.read_qual = b->read_qual + w.rb0;
         s.read_ins = b->read_ins ? b->read_ins + w.rb0 : nullptr;
         s.read_del = b->read_del ? b->read_del + w.rb0 : nullptr;
         s.read_gcp = b->read_gcp ? b->read_gcp + w.rb0 : nullptr;
-        s.read_off = roff.data();
+        s.read_off = in.roff.data();
         s.read_len = b->read_len + w.r0;
         s.hap_bases = b->hap_bases + w.hb0;
-        s.hap_off = hoff.data();
+        s.hap_off = in.hoff.data();
         s.hap_len = b->hap_len + w.h0;
         s.pair_read = cross ? nullptr : b->pair_read + w.p0;
         s.pair_hap = cross ? nullptr : b->pair_hap + w.p0;
-        phmm_read_prep prep_k;
         if (b->prep) {
-            prep_k = *b->prep;
-            prep_k.read_mapq = b->prep->read_mapq ? b->prep->read_mapq + w.r0 : nullptr;
-            s.prep = &prep_k;
+            in.prep_k = *b->prep;
+            in.prep_k.read_mapq = b->prep->read_mapq ? b->prep->read_mapq + w.r0 : nullptr;
+            s.prep = &in.prep_k;
         }
-        UploadOpts opt;
-        opt.stream = up;
-        opt.caller_synchronised = true;  // slot `slot` held chunk k - S: collected (see above), so its sweep is long over
-        opt.read_bias = cross ? 0 : w.r0;
-        opt.hap_bias = cross ? 0 : w.h0;
+        in.opt = UploadOpts();
+        in.opt.stream = up;
+        in.opt.caller_synchronised = true;  // the slot held chunk k - S: collected, so its sweep is long over
+        in.opt.read_bias = cross ? 0 : w.r0;
+        in.opt.hap_bias = cross ? 0 : w.h0;
+        in.clock = PhaseClock();
+        struct PhaseScope
+        {
+            explicit PhaseScope(PhaseClock *p) { g_phase = p; }
+            ~PhaseScope() { g_phase = nullptr; }
+        } phase_scope(tracing ? &in.clock : nullptr);
+        const int rc = upload_prepare(c, &s, rb, in.opt, scratch);
+        in.t_b = tracing ? now_us() : 0.0;
+        return rc;
+    };
+    std::atomic<bool> scratch_busy[8];
+    for (auto &f : scratch_busy) f.store(false);
+    auto slot_is_free = [&](size_t k) { return collected + S > k || producer_failed || collector_rc != PHMM_OK; };
+    if (n_prep) {
+        c->prep_pool->set_hot(true);
+        c->prep_pool->begin((unsigned)n_chunks, [&, n_prep](unsigned k) {
+            (void)n_prep;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return slot_is_free(k); });
+                if (producer_failed || collector_rc != PHMM_OK) {
+                    prepared[k] = PHMM_E_INVALID;
+                    prepared_msg[k] = "phmm_compute: the chunk pipeline stopped early";
+                    lk.unlock();
+                    cv.notify_all();
+                    return;
+                }
+            }
+            phmm_detail::HookScope hooks;
+            phmm_detail::t_serial = true;
+            int rc = PHMM_OK;
+            try {
+                // a binning scratch of the context for the duration of this chunk (at most 8 workers: there is always a free one)
+                unsigned mine = 0;
+                for (;; mine = (mine + 1) % 8u) {
+                    bool expected = false;
+                    if (scratch_busy[mine].compare_exchange_strong(expected, true)) break;
+                }
+                struct Release
+                {
+                    std::atomic<bool> &f;
+                    ~Release() { f.store(false); }
+                } release{scratch_busy[mine]};
+                rc = prepare(k, c->prep_scratch[mine]);
+            }
+            catch (...) {
+                rc = fail(PHMM_E_NOMEM, "phmm_compute: a prepare worker ran out of memory");
+            }
+            phmm_detail::t_serial = false;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                prepared[k] = rc;
+                if (rc != PHMM_OK) prepared_msg[k] = g_err;  // (thread-local: carry the text over)
+            }
+            cv.notify_all();
+        });
+    }
+    struct PrepJoiner  // whichever way this function returns, the prepare workers are through with the job first
+    {
+        phmm_detail::HostPool *pool;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &failed;
+        bool ok = false;
+        ~PrepJoiner()
+        {
+            if (!pool) return;
+            if (!ok) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    failed = true;
+                }
+                cv.notify_all();
+            }
+            pool->end();
+            pool->set_hot(false);
+        }
+    } prep_joiner{n_prep ? c->prep_pool : nullptr, mu, cv, producer_failed};
+
+    phmm_detail::PoolScope pool(c->pack_pool);
+    if (c->fin_pool) c->fin_pool->set_hot(true);
+    struct CoolDown
+    {
+        phmm_detail::HostPool *p;
+        ~CoolDown() { if (p) p->set_hot(false); }
+    } cool_down{c->fin_pool};
+    for (size_t k = 0; k < n_chunks; ++k) {
+        const ChunkWindow &w = plan[k];
+        const int slot = (int)(k % S);
+        phmm_resident *rb = c->chunk_slot[slot];
+        ChunkInput &in = input[slot];
+        if (n_prep) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return prepared[k] >= 0; });
+            if (prepared[k] != PHMM_OK) return fail(prepared[k], "%s", prepared_msg[k].c_str());
+            if (collector_rc != PHMM_OK) break;
+        }
+        else {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return slot_is_free(k); });
+                if (collector_rc != PHMM_OK) break;
+            }
+            const int rc = prepare(k, c->bin_scratch);
+            if (rc != PHMM_OK) return rc;
+        }
+        const double t_e = trace ? now_us() : 0.0;
+        UploadOpts opt = in.opt;
         // The copy travels on the upload stream (DMA engines: it runs beside the previous chunk's sweep); the set-up launch goes on
         // the context's stream, in front of this chunk's sweep.  On the upload stream it would not start before the previous sweep
         // has handed out its last workgroup -- small kernels of another queue are starved by a grid that fills the chip -- and the
@@ -388,8 +517,9 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
             LaneSwap(phmm_context *c_, bool on_) : c(c_), on(on_) { if (on) swap_sets(); }
             ~LaneSwap() { if (on) swap_sets(); }
         } lane_swap(c, two_lanes && async_upload && (k & 1));
-        int rc = upload_into(c, &s, rb, opt);
+        int rc = upload_enqueue(c, rb, opt);
         if (rc != PHMM_OK) return rc;
+        PHASE(3);
         // where the sums go: straight into the slot's pinned result block (the kernels write host memory over PCIe: no copy, no
         // cross-stream event between two sweeps), or -- PHMM_CHUNK_RESULTS_BY_COPY=1 -- into HBM and from there by a copy
         const uint64_t n = rb->n_pairs;
@@ -423,9 +553,9 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         cv.notify_all();
         if (trace) {
             PHASE(5);
-            fprintf(stderr, "phmm chunk %zu: %llu pairs, packed and enqueued %.0f..%.0f us (validate %.0f pack %.0f bin %.0f copy+setup %.0f sweep-enqueue %.0f results-enqueue %.0f)\n",
-                    k, (unsigned long long)(w.p1 - w.p0), t_a, now_us(), chunk_clock.us[0], chunk_clock.us[1], chunk_clock.us[2], chunk_clock.us[3],
-                    chunk_clock.us[4], chunk_clock.us[5]);
+            fprintf(stderr, "phmm chunk %zu: %llu pairs, prepared %.0f..%.0f us (validate %.0f pack %.0f bin %.0f), enqueued %.0f..%.0f us (copy+setup %.0f sweep %.0f results %.0f)\n",
+                    k, (unsigned long long)(w.p1 - w.p0), in.t_a, in.t_b, in.clock.us[0], in.clock.us[1], in.clock.us[2], t_e, now_us(),
+                    chunk_clock.us[3], chunk_clock.us[4], chunk_clock.us[5]);
         }
     }
     if (two_lanes && c->lane2.stream) {  // the device span of the call ends when both lanes are through
@@ -438,6 +568,7 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         cv.wait(lk, [&] { return collected >= enqueued || collector_rc != PHMM_OK; });
     }
     joiner.ok = enqueued == n_chunks;
+    prep_joiner.ok = joiner.ok;
     if (collector_rc != PHMM_OK) return fail(collector_rc, "%s", collector_msg.c_str());
     if (enqueued != n_chunks) return fail(PHMM_E_INVALID, "phmm_compute: the chunk pipeline stopped early");
     if (stats) {

@@ -31,6 +31,7 @@ constexpr int kStripedGroupsPerBlock = 4;  // a team (1, 4 or 8 waves) of the st
 // word so that a window read [w, w+1] at the last sweep step (column H + 15) stays inside the plane
 __host__ __device__ inline uint32_t planes_words(uint32_t hap_len) { return ((hap_len + 14u) >> 5) + 2u; }
 
+constexpr int kMaxRescueQueuesPerLaunch = 16;
 struct KernelArgs
 {
     // read table (raw phred bytes, ::TestCase semantics, core/common.h:13-24)
@@ -60,12 +61,42 @@ struct KernelArgs
     // region -- which share their reads and haplotypes -- sit next to each other in the processing order: with runs of 64 workgroups
     // (1 024 pairs) per XCD a region's bytes are fetched into one L2 instead of eight.
     uint32_t xcd_run_log2;
+    // fp64 re-run over SEVERAL rescue queues in one launch (striped kernels; n_rescue_queues = 0: the one queue n_pairs_dev counts).
+    // `order` is then the batch's whole rescue list, `rescue_count` the base of its counters; queue i of the launch is counter
+    // rescue_queue[i] and begins at rescue_base[i] of the list.  The teams stride over the queues' pairs kGroups at a time, every
+    // group of kGroups from ONE queue (pairs of one length class re-run in step).  A batch of mixed lengths has a queue per class;
+    // one launch each was thirteen launches per pass, nearly all of them empty, 5-50 us apiece at every chunk boundary of a one-shot call.
+    uint32_t n_rescue_queues;
+    uint32_t rescue_queue[kMaxRescueQueuesPerLaunch];
+    uint32_t rescue_base[kMaxRescueQueuesPerLaunch];
 };
 
 // lanes_per_pair 16: rows_per_lane = ceil(R / 16) in 1..kMaxRowsPerLane; 64: ceil(R / 64) in 1..kMaxRowsPerLaneWide
 // uniform_gop (only with uniform_gcp): every base of the batch has the same gap-open quality too -> the variant that shares p_mm / p_mx
 hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool uniform_gcp, const KernelArgs &a, hipStream_t s,
                                bool uniform_gop = false);
+// Ragged launches (pairhmm_kernels_ragged.hip): ONE launch over several rows-per-lane classes of a batch with mixed read lengths.
+// Every workgroup belongs to one class; the classes are listed in launch order (longest rows first).  KernelArgs::order / rescue_list /
+// rescue_count are the batch's whole arrays, n_pairs is not read.
+constexpr int kRaggedMaxSegs = 16;
+struct RaggedSeg
+{
+    uint32_t wg_first;   // first workgroup of the class in the launch (in processing order, before the XCD-local remap)
+    uint32_t pos_first;  // the class's range of `order`: [pos_first, pos_first + count)
+    uint32_t count;
+    uint32_t rows;       // rows per lane of the class's sweep
+    uint32_t queue;      // its rescue queue (index into rescue_count) ...
+    uint32_t list_base;  // ... and where that queue's list begins in rescue_list
+};
+struct RaggedArgs
+{
+    uint32_t n_seg, n_wg;  // classes, workgroups in all
+    RaggedSeg seg[kRaggedMaxSegs];
+};
+// which ragged kernel a class belongs to (classes of one range share a kernel: the same occupancy target); -1: none
+int ragged_range_of(int rows_per_lane, int lanes_per_pair, bool uniform_gop);
+// uniform gap-continuation penalty and deletion == insertion gap-opens are required (the Rovaca case); uniform_gop as in launch_systolic_f32
+hipError_t launch_systolic_ragged_f32(int lanes_per_pair, bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
 // striped ("team") kernels: a workgroup of waves_per_team waves (1, 4 or 8) sweeps four pairs; lds_words_per_group is
 // kPlanes * planes_words(longest haplotype of the launch); carry holds 3 * carry_stride values per (team, wave, group).
 // lanes_per_pair: 16 (four pairs per wave) or 64 (one pair per wave)

@@ -131,10 +131,9 @@ struct phmm_context
     // big one-shot batches are cut into chunks that go round three resident slots: chunk k is binned, packed and uploaded (on
     // side[2]) while chunk k - 1 is swept and chunk k - 2 is converted on the host by a collector thread (pairhmm_capi.cpp:
     // compute_chunked); the sums come back on a stream of their own so that the next sweep does not queue behind the copy
-    static constexpr int kChunkSlots = 3;
-    struct phmm_resident *chunk_slot[kChunkSlots] = {nullptr, nullptr, nullptr};
-    hipEvent_t chunk_up[kChunkSlots] = {nullptr, nullptr, nullptr}, chunk_swept[kChunkSlots] = {nullptr, nullptr, nullptr},
-               chunk_done[kChunkSlots] = {nullptr, nullptr, nullptr};
+    static constexpr int kChunkSlots = 6;
+    struct phmm_resident *chunk_slot[kChunkSlots] = {};
+    hipEvent_t chunk_up[kChunkSlots] = {}, chunk_swept[kChunkSlots] = {}, chunk_done[kChunkSlots] = {};
     hipStream_t down = nullptr;  // result copies of the chunked call
     // the chunked call's second sweep lane (odd chunks): a stream set of its own, swapped in for the duration of a chunk's enqueue, so
     // that one chunk's tail and the next one's head share the chip (compute_chunked)
@@ -144,6 +143,8 @@ struct phmm_context
         hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr}, done = nullptr;
     } lane2;
     phmm_detail::HostPool *pack_pool = nullptr, *fin_pool = nullptr;  // helper threads of the two sides of that pipeline
+    phmm_detail::HostPool *prep_pool = nullptr;  // its prepare workers: chunks k + 1, k + 2, ... are packed and binned while chunk k is enqueued
+    phmm_detail::BinScratch prep_scratch[8];     // one binning scratch per prepare worker
     phmm_detail::BinScratch bin_scratch;       // host scratch of the length binning, kept between calls
     std::vector<hipEvent_t> timing;            // event pool of phmm_sweep_timed
     struct phmm_stage *region_stage = nullptr; // phmm_compute_regions: the stage host buffers are copied into (pairhmm_stage.cpp)
@@ -230,13 +231,28 @@ struct CpuBatch
     phmm_batch view{};
 };
 
+// what upload_prepare (host) leaves for upload_enqueue (HIP): the layout of the resident's staging buffer
+struct UploadPlan
+{
+    size_t total = 0;
+    uint64_t read_bytes = 0, hap_bytes = 0, slots = 0;
+    size_t o_bases = 0, o_qual = 0, o_mapq = 0, o_ins = 0, o_del = 0, o_gcp = 0, o_roff = 0, o_rlen = 0, o_hap = 0, o_hoff = 0, o_hlen = 0,
+           o_pr = 0, o_ph = 0, o_order = 0, o_poff = 0, o_owner = 0;
+    bool has_prep = false, slim = false;
+    uint8_t gcp0 = 0;
+    phmm_read_prep prep{};
+};
+
 struct phmm_resident
 {
+    UploadPlan plan;
     CpuBatch *cpu = nullptr;
     ~phmm_resident() { delete cpu; }
     uint64_t n_pairs = 0, cells = 0;
     uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
     bool uniform_gcp = false, uniform_gop = false;
+    bool ragged = false;             // single-pass classes share launches (pairhmm_kernels_ragged.hip); decided at upload
+    uint32_t last_fp32_launches = 0; // launches of the last fp32 pass
     // inputs travel as ONE pinned staging buffer and ONE host-to-device copy per upload (a region-sized submission is
     // latency-bound: fifteen small copies cost more than the sweep); the views below point into `blob`
     HostBuf stage, out_stage;
@@ -337,7 +353,9 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb);
 int cpu_upload(phmm_context *c, const phmm_batch *b, phmm_resident *rb);
 int cpu_sweep(phmm_context *c, phmm_resident *rb);
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats);
-int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt);  // bin, pack, copy, set-up launch
+int upload_into(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt);  // bin, pack, copy, set-up launch: the two below
+int upload_prepare(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt, phmm_detail::BinScratch &bin_scratch);  // host only
+int upload_enqueue(phmm_context *c, phmm_resident *rb, const UploadOpts &opt);  // HIP calls only
 int phmm_create(int device_id, void *stream, phmm_context **out);
 int phmm_create_cpu(int n_threads, int allow_simd, phmm_context **out);
 void phmm_destroy(phmm_context *c);

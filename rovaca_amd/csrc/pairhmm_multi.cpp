@@ -81,7 +81,7 @@ int phmm_create_multi(const int *device_ids, int n_devices, phmm_multi **out)
     *out = nullptr;
     // PHMM_MULTI_ALLOW_SHARED_DEVICE=1 (tests, and bench.py --oversubscribe): a device may be listed several times -- every
     // entry still gets its own context, host thread and slice, so the whole N-slice path runs on a box with fewer than N GPUs
-    const bool shared_ok = getenv("PHMM_MULTI_ALLOW_SHARED_DEVICE") != nullptr;
+    const bool shared_ok = phmm_hook("PHMM_MULTI_ALLOW_SHARED_DEVICE") != nullptr;  // (dead without PHMM_ENABLE_TEST_HOOKS, like every hook)
     for (int i = 0; i < n_devices && !shared_ok; ++i)
         for (int j = 0; j < i; ++j)
             if (device_ids[i] == device_ids[j])

@@ -31,6 +31,7 @@ struct phmm_stage
     uint64_t n_pairs = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool in_flight = false;
+    bool valid = false;                        // the last submission succeeded: the results and pair_first describe it
     phmm_stage_params params{};
 };
 
@@ -48,7 +49,13 @@ void phmm_stage_destroy(phmm_context *c, phmm_stage *st)
     if (!st) return;
     if (c && !c->cpu) {
         (void)hipSetDevice(c->device);
+        // a submission in flight was enqueued on the context it was SUBMITTED on, which need not be `c` (the adapter creates its stages
+        // on one context and submits them on its dispatchers'): its event says when the kernels have stopped writing the stage
+        if (st->in_flight && st->ev1) (void)hipEventSynchronize(st->ev1);
         (void)hipStreamSynchronize(c->stream);
+    }
+    else if (st->in_flight && st->ev1) {
+        (void)hipEventSynchronize(st->ev1);
     }
     if (st->ev0) (void)hipEventDestroy(st->ev0);
     if (st->ev1) (void)hipEventDestroy(st->ev1);
@@ -173,7 +180,7 @@ int phmm_stage_get_view(const phmm_stage *st, phmm_stage_view *view, phmm_stage_
 
 // the checks every backend makes; fills pair_first / slot_first and the launches
 static int stage_plan(phmm_stage *st, uint32_t n_regions, uint32_t n_reads, uint32_t n_haps, std::vector<Bin> &bins, uint64_t *cells,
-                      uint32_t *max_read, uint32_t *max_hap, uint32_t *used_bytes)
+                      uint32_t *max_read, uint32_t *max_hap, uint32_t *used_bytes, bool ride_along)
 {
     const phmm_stage_caps &k = st->caps;
     const phmm_stage_view &v = st->view;
@@ -203,7 +210,7 @@ static int stage_plan(phmm_stage *st, uint32_t n_regions, uint32_t n_reads, uint
     bins.clear();
     uint64_t n_pairs = 0;
     const int rc = phmm_detail::bin_regions(v.regions, n_regions, v.read_len, n_reads, v.hap_len, n_haps, st->slot_first.data(),
-                                            st->pair_first.data(), bins, cells, &n_pairs);
+                                            st->pair_first.data(), bins, cells, &n_pairs, ride_along);
     if (rc != PHMM_OK) return rc;
     merge_striped_bins_of_one_shape(bins);
     if (n_pairs > k.max_pairs) return fail(PHMM_E_INVALID, "phmm_stage_submit: %llu pairs exceed the stage's capacity of %u", (unsigned long long)n_pairs, k.max_pairs);
@@ -221,7 +228,7 @@ static int cpu_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions,
     std::vector<Bin> bins;
     uint64_t cells = 0;
     uint32_t mr = 0, mh = 0, used = 0;
-    int rc = stage_plan(st, n_regions, n_reads, n_haps, bins, &cells, &mr, &mh, &used);
+    int rc = stage_plan(st, n_regions, n_reads, n_haps, bins, &cells, &mr, &mh, &used, true);
     if (rc != PHMM_OK) return rc;
     const phmm_stage_view &v = st->view;
     std::vector<uint32_t> pr(st->n_pairs), ph(st->n_pairs);
@@ -262,6 +269,7 @@ static int cpu_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions,
         st->raw32[p] = k.raw32[p];
         st->raw64[p] = k.raw64[p];
     }
+    st->valid = true;
     return PHMM_OK;
 }
 
@@ -273,11 +281,17 @@ int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint3
     if (c->cpu != st->cpu) return fail(PHMM_E_INVALID, "phmm_stage_submit: the stage belongs to the other kind of context");
     if (st->in_flight) return fail(PHMM_E_INVALID, "phmm_stage_submit: the previous submission has not been waited for");
     st->params = *prm;
+    // whatever the last submission left behind describes THAT batch: a submission that fails from here on leaves the stage empty, so
+    // that phmm_stage_log10 / _pair_first cannot hand out the previous batch's numbers as this one's
+    st->valid = false;
+    st->n_pairs = 0;
+    st->n_regions = 0;
     if (c->cpu) return cpu_stage_submit(c, st, n_regions, n_reads, n_haps, prm);
     HIP_TRY(hipSetDevice(c->device));
     phmm_resident &rb = st->rb;
     uint32_t mr = 0, mh = 0, used = 0;
-    int rc = stage_plan(st, n_regions, n_reads, n_haps, rb.bins, &rb.cells, &mr, &mh, &used);
+    rb.ragged = ragged_launches_for(true);  // a stage's reads are prepared on the device: always the Rovaca case
+    int rc = stage_plan(st, n_regions, n_reads, n_haps, rb.bins, &rb.cells, &mr, &mh, &used, !rb.ragged);
     if (rc != PHMM_OK) return rc;
     const phmm_stage_view &v = st->view;
     // ---- descriptors, right behind the used part of the arena: 32 bytes per read, 16 per haplotype ----
@@ -310,7 +324,10 @@ int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint3
     rb.max_hap_len = mh;
     rb.uniform_gop = prm->pcr_model == 0 && !phmm_hook("PHMM_NO_UNIFORM_GOP");  // no PCR model: every base keeps gap_open
     rb.last_rescued = 0;
-    if (st->n_pairs == 0) return PHMM_OK;
+    if (st->n_pairs == 0) {
+        st->valid = true;
+        return PHMM_OK;
+    }
     // ---- one copy, one set-up launch, then the passes of a resident batch ----
     uint8_t *d_arena = rb.blob.p;  // (the arena is the first thing in the blob)
     phmm::StageSetupArgs sa{};
@@ -335,18 +352,29 @@ int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint3
     sa.gap_open = prm->gap_open;
     sa.gap_cont = prm->gap_cont;
     sa.rescue_count = rb.rescue_count.p;
-    HIP_TRY(hipMemcpyAsync(d_arena, v.bytes, copy_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(st->ev0, c->stream));
-    HIP_TRY(phmm::launch_stage_setup(sa, c->stream));
-    rb.queue_is_empty = true;
-    rc = impl::sweep_fp32(c, &rb);
-    if (rc == PHMM_OK) rc = impl::sweep_rescue(c, &rb);
+    // from the copy on, every failure goes through one exit that drains the stream: whatever was enqueued reads the arena and writes
+    // the stage's results, and the caller is free to refill or destroy the stage as soon as this returns
+    auto enqueue = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(d_arena, v.bytes, copy_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(st->ev0, c->stream));
+        HIP_TRY(phmm::launch_stage_setup(sa, c->stream));
+        rb.queue_is_empty = true;
+        int r = impl::sweep_fp32(c, &rb);
+        if (r == PHMM_OK) r = impl::sweep_rescue(c, &rb);
+        if (r != PHMM_OK) return r;
+        HIP_TRY(hipEventRecord(st->ev1, c->stream));
+        return PHMM_OK;
+    };
+    rc = enqueue();
     if (rc != PHMM_OK) {
-        (void)hipStreamSynchronize(c->stream);  // whatever was enqueued reads the arena and writes the stage's results: let it end
+        (void)hipStreamSynchronize(c->stream);
+        for (int i = 0; i < c->n_side; ++i) (void)hipStreamSynchronize(c->side[i]);
+        st->n_pairs = 0;
+        st->n_regions = 0;
         return rc;
     }
-    HIP_TRY(hipEventRecord(st->ev1, c->stream));
     st->in_flight = true;
+    st->valid = true;
     return PHMM_OK;
 }
 
@@ -368,7 +396,7 @@ int phmm_stage_wait(phmm_context *c, phmm_stage *st, phmm_stats *stats)
         *stats = phmm_stats{};
         stats->cells = st->rb.cells;
         stats->kernel_ms = ms;
-        stats->n_launches = (uint32_t)st->rb.bins.size();
+        stats->n_launches = st->rb.last_fp32_launches ? st->rb.last_fp32_launches : (uint32_t)st->rb.bins.size();
         stats->max_rows_per_lane = st->rb.bins.empty() ? 0 : (uint32_t)st->rb.bins.back().rows_per_lane;
     }
     return PHMM_OK;
@@ -376,13 +404,14 @@ int phmm_stage_wait(phmm_context *c, phmm_stage *st, phmm_stats *stats)
 
 uint64_t phmm_stage_pair_first(const phmm_stage *st, uint32_t region)
 {
-    if (!st || region > st->n_regions) return 0;
+    if (!st || !st->valid || region > st->n_regions) return 0;
     return st->pair_first[region];
 }
 
 int phmm_stage_log10(const phmm_stage *st, uint64_t first_pair, uint64_t n, double *out, float *out_raw_f32, uint64_t *n_rescued)
 {
     if (!st) return fail(PHMM_E_INVALID, "phmm_stage_log10: null argument");
+    if (!st->valid) return fail(PHMM_E_INVALID, "phmm_stage_log10: the stage's last submission did not succeed (or there was none)");
     if (first_pair + n > st->n_pairs) return fail(PHMM_E_INVALID, "phmm_stage_log10: pairs [%llu, +%llu) of %llu", (unsigned long long)first_pair,
                                                    (unsigned long long)n, (unsigned long long)st->n_pairs);
     const float *r32 = st->raw32 + first_pair;

@@ -14,6 +14,16 @@
 #include "../../include/smithwaterman_hip.h"
 #include "sw_device.h"
 
+// Test and tuning hooks (SWHIP_*) are dead unless PHMM_ENABLE_TEST_HOOKS=1 is set -- the same master switch as the PairHMM library's
+// (pairhmm_binning.h): a production process that inherits SWHIP_FORCE_LANES must not run a slower kernel shape for it.
+// (SWHIP_BLOCKING_SYNC is an operating choice, read directly.)
+static const char *sw_hook(const char *name)
+{
+    const char *m = getenv("PHMM_ENABLE_TEST_HOOKS");
+    if (!m || !m[0] || (m[0] == '0' && m[1] == 0)) return nullptr;
+    return getenv(name);
+}
+
 static_assert(sizeof(swhip_alignment) == sizeof(swhip::Alignment), "device and ABI result structs must agree");
 
 namespace
@@ -127,7 +137,7 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
     constexpr uint64_t kWideMaxPairs = 2048;
     constexpr uint32_t kLdsFlagsMaxPairs = 768;  // 256 CUs x up to 3 workgroups of ~50 KB
     int forced_lanes = 0;
-    if (const char *e = getenv("SWHIP_FORCE_LANES")) forced_lanes = atoi(e);  // tests
+    if (const char *e = sw_hook("SWHIP_FORCE_LANES")) forced_lanes = atoi(e);  // tests
     std::vector<uint64_t> keys;  // class << 48 | (0xFFFF - len1) << 32 | pair
     keys.reserve(n);
     uint64_t cells = 0, worst_elems = 0;
@@ -156,7 +166,7 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
     // Small batches (everything one alignment per wave): a launch per columns-per-lane value costs a lone wave's sweep each, one after
     // the other on the stream, and a region whose reads were trimmed to different lengths has two or three of them.  A class rides along
     // with the next one up -- its alignments simply leave the upper lanes idle -- as long as that at most doubles its columns per lane.
-    if (n <= kWideMaxPairs && !getenv("SWHIP_NO_CLASS_MERGE")) {
+    if (n <= kWideMaxPairs && !sw_hook("SWHIP_NO_CLASS_MERGE")) {
         bool present[128] = {false};
         for (uint64_t key : keys) present[(key >> 48) & 127] = true;
         uint8_t to[128];
@@ -186,7 +196,7 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
     std::vector<uint64_t> bt_off(n, 0), scr_off(n, 0);
     uint64_t bt_words = 0, bt_peak = 0, scr_slots = 0;
     uint64_t kBtWordsPerLaunch = 1ull << 30;
-    if (const char *e = getenv("SWHIP_BT_WORDS_PER_LAUNCH")) kBtWordsPerLaunch = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // tests
+    if (const char *e = sw_hook("SWHIP_BT_WORDS_PER_LAUNCH")) kBtWordsPerLaunch = std::max<uint64_t>(1, strtoull(e, nullptr, 10));  // tests
     struct Launch
     {
         int lanes, k;
@@ -252,7 +262,7 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
     const size_t res_bytes = n * sizeof(swhip::Alignment);
     HIP_TRY(c->back.ensure(res_bytes));
     constexpr uint64_t kDirectCigarElems = 4ull << 20;  // 16 MB of pinned memory at most
-    const bool cigars_direct = worst_elems <= kDirectCigarElems && !getenv("SWHIP_CIGARS_BY_COPY");  // (the hook: tests)
+    const bool cigars_direct = worst_elems <= kDirectCigarElems && !sw_hook("SWHIP_CIGARS_BY_COPY");  // (the hook: tests)
     if (cigars_direct)
         HIP_TRY(c->back_cigars.ensure(worst_elems * 4));
     else
@@ -291,7 +301,7 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
         // and with several calls in flight -- the adapter's case -- they queue for it (30 workers x 4 regions in flight: 118 000
         // regions/s with, 126 000 without).
         const uint64_t bt_bytes = swhip::bt_words(l.max_len1, l.lanes, l.k) * 4;
-        const bool in_lds = l.lanes == 64 && l.count <= kLdsFlagsMaxPairs && a.lds_stride + bt_bytes <= 150u * 1024u && getenv("SWHIP_LDS_FLAGS");
+        const bool in_lds = l.lanes == 64 && l.count <= kLdsFlagsMaxPairs && a.lds_stride + bt_bytes <= 150u * 1024u && sw_hook("SWHIP_LDS_FLAGS");
         a.bt_in_lds = in_lds ? 1u : 0u;
         a.lds_bt_bytes = in_lds ? (uint32_t)bt_bytes : 0u;
         HIP_TRY(swhip::launch_sw(l.k, l.lanes, a, st));

@@ -44,6 +44,7 @@ def lib():
         L = C.CDLL(path)
         L.swhip_abi_version.restype = C.c_int
         L.swhip_last_error.restype = C.c_char_p
+        L.swhip_kernel_build_id.restype = C.c_char_p
         L.swhip_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.swhip_create.restype = C.c_int
         L.swhip_destroy.argtypes = [C.c_void_p]

@@ -4,6 +4,9 @@ import sys
 import numpy as np
 import pytest
 
+# the PHMM_* / SWHIP_* test hooks the suite flips are dead without the master switch (rovaca_amd/csrc/pairhmm_binning.h)
+os.environ.setdefault("PHMM_ENABLE_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

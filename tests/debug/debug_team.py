@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 if len(sys.argv) == 1:
     for lanes in ("16", "64"):
         for waves in ("1", "4"):
-            env = dict(os.environ, PHMM_FORCE_TEAM_LANES=lanes, PHMM_FORCE_TEAM_WAVES=waves)
+            env = dict(os.environ, PHMM_ENABLE_TEST_HOOKS="1", PHMM_FORCE_TEAM_LANES=lanes, PHMM_FORCE_TEAM_WAVES=waves)
             subprocess.run([sys.executable, __file__, "child"], env=env)
     sys.exit(0)
 import oracle

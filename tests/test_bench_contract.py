@@ -52,15 +52,17 @@ def test_device_line_has_roofline_and_cpu_baseline():
 def test_committed_pmc_counters_belong_to_the_committed_kernels():
     # profiles/hbm_traffic.json feeds roofline.traffic and roofline_issue on the bench line: it must have been collected from the
     # kernel sources in the tree (tools/profile_round.sh + tools/summarize_profiles.py after the last kernel change)
-    from rovaca_amd import kernel_source_id
+    from rovaca_amd import kernel_source_id, loaded_kernel_build_id
     pj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert loaded_kernel_build_id() == kernel_source_id(), "the built library is older than the kernel sources (or their flags): make -C rovaca_amd/csrc"
     assert pj.get("kernel_source_id") == kernel_source_id(), "stale PMC counters: re-run tools/profile_round.sh on the GPU box and tools/summarize_profiles.py"
     assert pj["c2"] > 0 and pj["c2_valu_wave_instructions"] > 0 and "pairhmm_systolic" in pj["c2_kernel"]
 
 
 def test_committed_smith_waterman_counters_belong_to_the_committed_kernel():
-    from rovaca_amd import sw_kernel_source_id
+    from rovaca_amd import loaded_sw_kernel_build_id, sw_kernel_source_id
     pj = json.load(open(os.path.join(ROOT, "profiles", "sw_counters.json")))
+    assert loaded_sw_kernel_build_id() == sw_kernel_source_id(), "the built library is older than the kernel sources (or their flags)"
     assert pj.get("kernel_source_id") == sw_kernel_source_id(), "stale PMC counters: re-run tools/profile_round.sh and tools/summarize_profiles.py"
     assert pj["valu_wave_instructions"] > 0 and "sw_kernel" in pj["kernel"]
 

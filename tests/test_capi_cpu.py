@@ -55,7 +55,7 @@ def test_sw_library_exports_every_declared_symbol_and_refuses_without_device():
     text = open(os.path.join(ROOT, "include", "smithwaterman_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = sorted(set(re.findall(r"\b(swhip_[a-z0-9_]+)\s*\(", text)))
-    assert names == ["swhip_abi_version", "swhip_align", "swhip_create", "swhip_destroy", "swhip_device_count", "swhip_last_error"]
+    assert names == ["swhip_abi_version", "swhip_align", "swhip_create", "swhip_destroy", "swhip_device_count", "swhip_kernel_build_id", "swhip_last_error"]
     L = swapi.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/smithwaterman_hip.h but not exported"

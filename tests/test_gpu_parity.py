@@ -15,6 +15,19 @@ pytestmark = pytest.mark.gpu
 TOL_LOG10 = 1e-5  # BASELINE.json north_star
 TOL_RESCUE = 1e-9  # fp64 vs scalar double oracle, same operation order
 
+# How the rows-per-lane classes of a mixed-length batch reach the device -- the same sweep of the same pair either way, so the same bits:
+# "ragged": the classes share launches, every workgroup picks its K (pairhmm_kernels_ragged.hip; the default for Rovaca-case batches);
+# "ride-along": one launch per class, small classes handed to the next class up (PHMM_NO_RAGGED; the default until round 3, and still
+# the plan of batches with general per-base gap penalties); "per-class": one launch per class, nothing merged.
+LAUNCH_PLANS = ("ragged", "ride-along", "per-class")
+
+
+def _set_launch_plan(monkeypatch, plan):
+    if plan != "ragged":
+        monkeypatch.setenv("PHMM_NO_RAGGED", "1")
+    if plan == "per-class":
+        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")
+
 
 @pytest.fixture(scope="module")
 def engine():
@@ -63,20 +76,18 @@ def test_config2_sample_150x300(engine):
     _check_against_oracle(engine, synth.make_config("c2", scale=0.02))
 
 
-@pytest.mark.parametrize("merge", [False, True])
+@pytest.mark.parametrize("launches", LAUNCH_PLANS)
 @pytest.mark.parametrize("lanes", [16, 64])
-def test_config3_sample_mixed_lengths(engine, lanes, merge, monkeypatch):
-    if not merge:
-        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # one launch per rows-per-lane value (small ones otherwise ride along)
+def test_config3_sample_mixed_lengths(engine, lanes, launches, monkeypatch):
+    _set_launch_plan(monkeypatch, launches)
     monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
     _check_against_oracle(engine, synth.make_config("c3", scale=0.02))
 
 
-@pytest.mark.parametrize("merge", [False, True])
+@pytest.mark.parametrize("launches", LAUNCH_PLANS)
 @pytest.mark.parametrize("lanes", [16, 64])
-def test_every_rows_per_lane_bin(engine, lanes, merge, monkeypatch):
-    if not merge:
-        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # one launch per rows-per-lane value (small ones otherwise ride along)
+def test_every_rows_per_lane_bin(engine, lanes, launches, monkeypatch):
+    _set_launch_plan(monkeypatch, launches)
     # read lengths 1..256 hit every K = ceil(R/16) instantiation, including exact multiples of 16, in both shapes of the
     # single-pass kernel: four pairs per wave (16 lanes each) and one pair per wave (64 lanes, K = ceil(R/64))
     monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
@@ -100,11 +111,10 @@ def test_every_rows_per_lane_bin(engine, lanes, merge, monkeypatch):
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
-@pytest.mark.parametrize("merge", [False, True])
+@pytest.mark.parametrize("launches", LAUNCH_PLANS)
 @pytest.mark.parametrize("lanes", [16, 64])
-def test_general_gap_parameters(engine, lanes, merge, monkeypatch):
-    if not merge:
-        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # one launch per rows-per-lane value (small ones otherwise ride along)
+def test_general_gap_parameters(engine, lanes, launches, monkeypatch):
+    _set_launch_plan(monkeypatch, launches)
     # per-base ins / del / gcp all different: exercises the non-uniform-gcp kernel variant
     monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
     rng = np.random.default_rng(6)
@@ -396,11 +406,10 @@ def test_band_kernel_pair_joining_late_beside_a_stripe_that_began_mid_row(engine
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
-@pytest.mark.parametrize("merge", [False, True])
+@pytest.mark.parametrize("launches", LAUNCH_PLANS)
 @pytest.mark.parametrize("lanes", [16, 64])
-def test_uniform_gap_open_kernel_is_the_general_one(engine, lanes, merge, monkeypatch):
-    if not merge:
-        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # one launch per rows-per-lane value (small ones otherwise ride along)
+def test_uniform_gap_open_kernel_is_the_general_one(engine, lanes, launches, monkeypatch):
+    _set_launch_plan(monkeypatch, launches)
     # batches with one gap-open quality throughout (PCR-free data, the synthetic configs) take the variant that shares p_mm / p_mx
     # and reuses M * p_mx for the Y of the next step: same bits as the Rovaca-case kernel (PHMM_NO_UNIFORM_GOP=1) and as the oracle,
     # for every rows-per-lane value, with padding rows, N and foreign symbols; a batch with ONE deviating base must not take it
@@ -456,3 +465,59 @@ def test_xcd_local_workgroup_order_changes_no_result(engine, monkeypatch):
         k = np.random.default_rng(n_regions).choice(b.n_pairs, min(b.n_pairs, 300), replace=False)
         want = oracle.batch(b.subset(k))[0]
         assert np.array_equal(raw[k].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("lanes", [16, 64])
+@pytest.mark.parametrize("pcr_model", [0, 3])
+def test_ragged_launches_are_the_per_class_launches(engine, lanes, pcr_model, monkeypatch):
+    # One launch for many rows-per-lane classes (pairhmm_kernels_ragged.hip) against one launch per class (PHMM_NO_RAGGED), same batch:
+    # every class 1..16, classes with a single pair, a class that fills exactly one workgroup and one that spills into a second, rescued
+    # pairs in several classes (noisy reads), each class with its own rescue queue (PHMM_FORCE_QUEUE_PER_CLASS) or all in one, the
+    # XCD-local workgroup order forced onto the ragged grid, both kernel families (one gap-open quality: PCR model NONE; per-base
+    # gap-opens: CONSERVATIVE) through device-side read preparation.  Identical bits, identical rescue counts, fewer launches.
+    monkeypatch.setenv("PHMM_FORCE_LANES", str(lanes))
+    rng = np.random.default_rng(90 + pcr_model)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    haps = [acgt[rng.integers(0, 4, int(n))] for n in rng.integers(260, 520, 12)]
+    reads = []
+    lens = list(rng.integers(1, 257, 150)) + [16] * 16 + [33] * 17 + [256, 255, 241, 240, 1, 2]
+    for R in lens:
+        R = int(R)
+        hap = haps[int(rng.integers(0, len(haps)))]
+        a0 = int(rng.integers(0, len(hap) - R + 1))
+        seq = hap[a0:a0 + R].copy()
+        noise = 0.25 if rng.random() < 0.2 else 0.01
+        bad = rng.random(R) < noise
+        seq[bad] = acgt[rng.integers(0, 4, int(bad.sum()))]
+        q = rng.choice(np.array([8, 20, 30, 37], np.uint8), R)
+        g = np.full(R, 45, np.uint8)
+        reads.append((seq, q, g, g.copy(), np.full(R, 10, np.uint8)))
+    b = Batch.from_lists(reads, haps)  # the full cross product
+    mapq = np.full(b.n_reads, 60, np.uint8)
+    prep = (mapq, 0, pcr_model)  # (no quality threshold: the oracle below sees the same qualities)
+    for per_class_queues in (False, True):
+        if per_class_queues:
+            monkeypatch.setenv("PHMM_FORCE_QUEUE_PER_CLASS", "1")
+        monkeypatch.setenv("PHMM_NO_RAGGED", "1")
+        monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")  # (or the small classes of this batch would all ride along in one launch)
+        raw0, l10_0, st0 = engine.compute(b, prep=prep)
+        monkeypatch.delenv("PHMM_NO_RAGGED")
+        monkeypatch.delenv("PHMM_NO_BIN_MERGE")
+        raw1, l10_1, st1 = engine.compute(b, prep=prep)
+        monkeypatch.setenv("PHMM_XCD_LOCAL_MIN_PAIRS", "1")
+        raw2, l10_2, st2 = engine.compute(b, prep=prep)
+        monkeypatch.delenv("PHMM_XCD_LOCAL_MIN_PAIRS")
+        # the fp64 re-run: queues that take the same kernel share a launch (the default) or get one launch each
+        monkeypatch.setenv("PHMM_NO_RESCUE_MERGE", "1")
+        raw3, l10_3, st3 = engine.compute(b, prep=prep)
+        monkeypatch.delenv("PHMM_NO_RESCUE_MERGE")
+        for raw, l10, st in ((raw1, l10_1, st1), (raw2, l10_2, st2), (raw3, l10_3, st3)):
+            assert np.array_equal(raw.view(np.uint32), raw0.view(np.uint32))
+            assert np.array_equal(l10, l10_0, equal_nan=True)
+            assert int(st.n_rescued) == int(st0.n_rescued) > 0
+        assert int(st1.n_launches) < int(st0.n_launches) and int(st1.n_launches) <= 3
+    # and the oracle, on a sample (the batch prepared on the host the same way)
+    if pcr_model == 0:
+        k = rng.choice(b.n_pairs, 400, replace=False)
+        want = oracle.batch(b.subset(k))[0]
+        assert np.array_equal(raw1[k].view(np.uint32), want.view(np.uint32))

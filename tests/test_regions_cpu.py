@@ -53,6 +53,13 @@ def test_small_launches_ride_along_with_the_next_class(monkeypatch):
     monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")
     _, plain = capi.plan_bins(b, cross=True)
     assert [(r, c) for r, _, c in plain] == [(3, 50), (5, 50), (7, 50), (8, 50), (9, 50), (10, 3000)]
+    # ... and without the master switch no hook is honoured (a production process that inherits PHMM_NO_BIN_MERGE keeps the merge)
+    monkeypatch.delenv("PHMM_ENABLE_TEST_HOOKS")
+    _, dead = capi.plan_bins(b, cross=True)
+    assert [(r, c) for r, _, c in dead] == [(10, 65 * 50)]
+    monkeypatch.setenv("PHMM_ENABLE_TEST_HOOKS", "0")
+    assert capi.plan_bins(b, cross=True)[1] == dead
+    monkeypatch.setenv("PHMM_ENABLE_TEST_HOOKS", "1")
     monkeypatch.delenv("PHMM_NO_BIN_MERGE")
     reads = [(np.full(n, 65, np.uint8),) * 5 for n in [100] * 170 + [151] * 170 + [250]]
     b = Batch.from_lists(reads, haps)

@@ -14,13 +14,13 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   echo "pmc $grp done"
 done
 # the same batch through the general kernel (per-base gap-opens: what a run under the default PCR model takes)
-export PHMM_NO_UNIFORM_GOP=1
+export PHMM_ENABLE_TEST_HOOKS=1 PHMM_NO_UNIFORM_GOP=1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcpcr_$tag -o pmc -- python3 bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-adapter > $OUT/pmcpcr_$tag.log 2>&1
   echo "pmc (general kernel) $grp done"
 done
-unset PHMM_NO_UNIFORM_GOP
+unset PHMM_NO_UNIFORM_GOP PHMM_ENABLE_TEST_HOOKS
 find $OUT -name "*.csv" | head -30
 # Smith-Waterman aligner: kernel trace of bench.py --config sw
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sw -o sw -- python3 bench.py --config sw --no-cpu-baseline > $OUT/bench_sw.log 2>&1

@@ -16,6 +16,7 @@ eng = capi.Engine(0)
 eng.compute(b.subset(range(1000)))
 out = (np.zeros(b.n_pairs, np.float32), np.zeros(b.n_pairs, np.float64))
 for pl in plans:
+    os.environ["PHMM_ENABLE_TEST_HOOKS"] = "1"
     os.environ["PHMM_CHUNK_WEIGHTS"] = pl
     for _ in range(3):
         eng.compute(b, out=out)
