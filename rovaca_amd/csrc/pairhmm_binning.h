@@ -38,6 +38,7 @@ constexpr uint32_t kMaxLen = 1u << 20;
 constexpr uint64_t kQueuePerClassMinPairs = 50000;  // batches above this re-run each single-pass class from its own queue
 constexpr uint32_t kXcdLocalMinPairs = 1u << 18;  // single-pass launches from this many pairs on order their workgroups XCD-locally
 constexpr uint32_t kWideMaxPairs = 1536;       // single-pass launches up to this many pairs run one pair per wave
+constexpr uint64_t kRaggedUniformBelowPairs = 1u << 18;  // ragged launches below this take the uniform-budget kernel (one launch for all classes)
 constexpr uint32_t kRescueMaxTeams = 4096;    // workgroups of the fp64 re-run (they stride over the rescue queue)
 constexpr uint32_t kStripedMaxTeams = 4096;   // workgroups of the striped kernel per launch, divided by waves per team
 

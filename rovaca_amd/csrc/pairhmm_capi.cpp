@@ -175,6 +175,19 @@ void phmm_destroy(phmm_context *c)
         }
         if (c->lane2.join[i]) (void)hipEventDestroy(c->lane2.join[i]);
     }
+    if (c->rescue_lane.stream) {
+        (void)hipStreamSynchronize(c->rescue_lane.stream);
+        (void)hipStreamDestroy(c->rescue_lane.stream);
+    }
+    if (c->rescue_lane.fork) (void)hipEventDestroy(c->rescue_lane.fork);
+    if (c->rescue_lane.done) (void)hipEventDestroy(c->rescue_lane.done);
+    for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+        if (c->rescue_lane.side[i]) {
+            (void)hipStreamSynchronize(c->rescue_lane.side[i]);
+            (void)hipStreamDestroy(c->rescue_lane.side[i]);
+        }
+        if (c->rescue_lane.join[i]) (void)hipEventDestroy(c->rescue_lane.join[i]);
+    }
     delete c->pack_pool;
     delete c->fin_pool;
     delete c->prep_pool;
@@ -657,7 +670,7 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
     struct FpLaunch
     {
         size_t first, n;  // bins [first, first + n)
-        int lanes;        // single-pass launches: lanes per pair (16 / 64); 0: not decided here (striped, or the per-bin rule)
+        int lanes;        // single-pass launches: lanes per pair (16 / 64); 0: not decided here (striped, or the per-bin rule); -1: uniform-budget ragged kernel (16 or 32 per class)
     };
     uint32_t wide_max = kWideMaxPairs;
     if (const char *f = phmm_hook("PHMM_WIDE_MAX_PAIRS")) wide_max = (uint32_t)std::max(0, atoi(f));  // tuning
@@ -682,6 +695,17 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         for (; j < rb->bins.size() && rb->bins[j].rows_per_lane > 0; ++j) total += rb->bins[j].count;
         // few pairs in the whole run: one pair per wave (see the one-launch-per-bin rule below)
         const int lanes = forced_lanes ? forced_lanes : total <= wide_max ? 64 : 16;
+        // A run that is not huge -- a chunk of a one-shot call, a stage -- is ONE launch of the uniform-budget kernel (lanes = -1 here):
+        // every class at four waves per SIMD, the classes whose 16-lane sweep needs more than 128 registers as 32 lanes per pair
+        // (pairhmm_kernels_ragged.hip says why: kernels of different budgets side by side cost every chunk 16 %).  From 2^18 pairs on
+        // the K-range kernels below are better: their mix is over after the first third of the pass.
+        uint64_t uniform_below = kRaggedUniformBelowPairs;
+        if (const char *f = phmm_hook("PHMM_RAGGED_UNIFORM_BELOW")) uniform_below = (uint64_t)std::max(0ll, atoll(f));  // tests, tuning
+        if (lanes == 16 && total < uniform_below && j - i > 1 && j - i <= (size_t)phmm::kRaggedMaxSegs) {
+            launches.push_back(FpLaunch{i, j - i, -1});
+            i = j;
+            continue;
+        }
         for (size_t k = i; k < j;) {
             const int range = phmm::ragged_range_of(lanes == 64 ? wide_rows(rb->bins[k]) : rb->bins[k].rows_per_lane, lanes, rb->uniform_gop);
             size_t e = k + 1;
@@ -693,6 +717,13 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         }
         i = j;
     }
+    // Longest workgroups first: the striped launches, then the single-pass ones by descending rows per lane.  The launches of a pass run
+    // side by side on different streams, and a kernel with a bigger register budget cannot move into the hole a finished wave of a
+    // smaller one leaves (168 or 200 VGPRs do not fit into a freed 128): launched last, the big-K kernels of a chunk were starved until the
+    // small-K kernel had drained and then ran alone, a round and a half of the chip at two or three waves per SIMD (rocprofv3 time line
+    // of config 3's one-shot call, round 4: 1.0-1.6 ms for a quarter of a chunk's cells).  Launched first they are resident before the
+    // small-K grid arrives, and that one -- which fits into any hole -- fills the chip behind them and makes up the tail.
+    std::reverse(launches.begin(), launches.end());
     rb->last_fp32_launches = (uint32_t)launches.size();
     const bool fan_out = launches.size() > 1;
     if (fan_out) {
@@ -733,14 +764,17 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
             phmm::RaggedArgs m{};
             uint32_t wg = 0, lds_words = 0;
             uint64_t total = 0;
-            const uint32_t per_wg = L.lanes == 64 ? 1u : (uint32_t)phmm::kBlockThreads / 16u;
+            const bool uniform = L.lanes < 0;
             for (size_t q = L.n; q-- > 0;) {
                 const Bin &sb = rb->bins[L.first + q];
                 phmm::RaggedSeg &sg = m.seg[m.n_seg++];
+                const int seg_lanes = uniform ? phmm::ragged_uniform_lanes_of(sb.rows_per_lane, rb->uniform_gop) : L.lanes;
+                const uint32_t per_wg = seg_lanes == 64 ? 1u : (uint32_t)phmm::kBlockThreads / (uint32_t)seg_lanes;
                 sg.wg_first = wg;
                 sg.pos_first = sb.first;
                 sg.count = sb.count;
-                sg.rows = (uint32_t)(L.lanes == 64 ? wide_rows(sb) : sb.rows_per_lane);
+                sg.rows = (uint32_t)(seg_lanes == 64 ? wide_rows(sb) : seg_lanes == 32 ? (int)((sb.max_read_len + 31) / 32) : sb.rows_per_lane);
+                sg.lanes = (uint32_t)seg_lanes;
                 sg.queue = (uint32_t)sb.queue;
                 sg.list_base = sb.queue == 0 ? 0u : sb.first;
                 wg += (sb.count + per_wg - 1) / per_wg;
@@ -753,8 +787,11 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
             a.lds_words_per_group = lds_words;
             a.rescue_list = rb->rescue_list.p;
             a.rescue_count = rb->rescue_count.p;
-            if (L.lanes == 16 && total >= xcd_min && xcd_local) a.xcd_run_log2 = 6;
-            HIP_TRY(phmm::launch_systolic_ragged_f32(L.lanes, rb->uniform_gop, a, m, stream));
+            if (L.lanes != 64 && total >= xcd_min && xcd_local) a.xcd_run_log2 = 6;
+            if (uniform)
+                HIP_TRY(phmm::launch_systolic_ragged_uniform_f32(rb->uniform_gop, a, m, stream));
+            else
+                HIP_TRY(phmm::launch_systolic_ragged_f32(L.lanes, rb->uniform_gop, a, m, stream));
         }
         else if (bin.rows_per_lane > 0) {
             // Few pairs: one pair per wave.  Four per wave would occupy count / 4 of the chip's 1024 SIMDs with one slow wave
@@ -790,8 +827,15 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
     return PHMM_OK;
 }
 
-int sweep_rescue(phmm_context *c, phmm_resident *rb)
+int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLane *on)
 {
+    // the stream set the launches go to: the context's own, or the one handed in (the chunk pipeline's collector thread re-runs a
+    // chunk's underflowed pairs on a lane of its own while the calling thread keeps enqueuing sweeps on the context's)
+    hipStream_t s_main = on ? on->stream : c->stream;
+    hipStream_t const *s_side = on ? on->side : c->side;
+    hipEvent_t s_fork = on ? on->fork : c->fork;
+    hipEvent_t const *s_join = on ? on->join : c->join;
+
     // The fp64 re-run of the pairs the fp32 kernels queued.  Nothing comes back to the host between the two passes: the
     // team kernel reads the queue length from device memory and its workgroups stride over the queue (all of them leave
     // at once when it is empty), so a pass is one asynchronous chain on the context's stream.  One launch per queue (the
@@ -878,13 +922,13 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb)
     HIP_TRY(rb->carry64.alloc(carry_total));
     const bool fan_out = launches.size() > 1;
     if (fan_out) {
-        HIP_TRY(hipEventRecord(c->fork, c->stream));
-        for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
+        HIP_TRY(hipEventRecord(s_fork, s_main));
+        for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(s_side[i], s_fork, 0));
     }
     int nth = 0;
     for (const RescueLaunch &L : launches) {
         const int lane = fan_out ? nth++ % (c->n_side + 1) : 0;
-        hipStream_t st = lane == 0 ? c->stream : c->side[lane - 1];
+        hipStream_t st = lane == 0 ? s_main : s_side[lane - 1];
         phmm::KernelArgs a{};
         a.read_bases = rb->read_bases.p;
         a.read_qual = rb->read_qual.p;
@@ -923,8 +967,8 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb)
     }
     if (fan_out) {
         for (int i = 0; i < c->n_side; ++i) {
-            HIP_TRY(hipEventRecord(c->join[i], c->side[i]));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->join[i], 0));
+            HIP_TRY(hipEventRecord(s_join[i], s_side[i]));
+            HIP_TRY(hipStreamWaitEvent(s_main, s_join[i], 0));
         }
     }
     return PHMM_OK;

@@ -169,6 +169,20 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
             HIP_TRY(hipEventCreateWithFlags(&c->lane2.join[i], hipEventDisableTiming));
         }
     }
+    // The fp64 re-run of a chunk is NOT part of its device chain: the collector thread sees the chunk's fp32 sums on the host, and only
+    // when one of them underflowed does it launch that chunk's re-run, on a lane of its own (below).  Enqueued behind every sweep the
+    // re-run launches -- four per chunk of mixed lengths, nearly always empty -- each had to push thousands of workgroups with a 256-register
+    // budget through a chip full of the other lane's sweep, 50-700 us during which the lane could not start its next chunk: consecutive
+    // chunks stopped overlapping and every one paid its own ramp and tail (rocprofv3 time line of config 3, round 4: 10.1 ms of device
+    // time for 7.9 ms of sweeps).
+    if (!c->rescue_lane.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->rescue_lane.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->rescue_lane.fork, hipEventDisableTiming));
+        for (int i = 0; i < c->n_side; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->rescue_lane.side[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->rescue_lane.join[i], hipEventDisableTiming));
+        }
+    }
     hipStream_t up = c->side[phmm_context::kSideStreams - 1];  // not used by the sweeps (n_side defaults to 2 of 3)
     if (c->n_side >= phmm_context::kSideStreams) up = c->stream;
     hipStream_t down = c->down;
@@ -208,40 +222,50 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         const uint8_t *st = static_cast<const uint8_t *>(rb->out_stage.p);
         const float *rp = reinterpret_cast<const float *>(st);
         const double *r64 = reinterpret_cast<const double *>(st + off64);
-        bool want64 = true;  // results written by the kernels straight into the pinned stage: the fp64 sums are there already
-        if (!direct) {
-            const uint32_t *counts = reinterpret_cast<const uint32_t *>(st + off_cnt);
-            rb->last_rescued = 0;
-            for (int qi = 0; qi < kQueues; ++qi) rb->last_rescued += counts[qi];
-            want64 = out_log10 && rb->last_rescued;
-            if (want64) {
-                // the rescue kernels of this chunk are done (the event above follows them); the copy runs beside the next sweep
-                HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(st) + off64, rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, down));
-                HIP_TRY(hipStreamSynchronize(down));
-            }
-        }
         if (out_raw_f32) memcpy(out_raw_f32 + w.p0, rp, n * sizeof(float));
+        // pass 1: the accepted pairs' log10 (pairhmm_internal.cpp:577-585), and where the underflowed ones are
         std::atomic<uint64_t> n_resc{0};
+        std::mutex resc_mu;
+        std::vector<uint32_t> rescued;
+        double *dst = out_log10 ? out_log10 + w.p0 : nullptr;
         {
-            double *dst = out_log10 ? out_log10 + w.p0 : nullptr;
-            auto finalize = [&](uint64_t lo, uint64_t hi, unsigned) {  // pairhmm_internal.cpp:577-585
+            auto finalize = [&](uint64_t lo, uint64_t hi, unsigned) {
+                uint32_t mine[64];
+                uint32_t m = 0;
                 uint64_t resc = 0;
+                auto flush = [&] {
+                    std::lock_guard<std::mutex> lk(resc_mu);
+                    rescued.insert(rescued.end(), mine, mine + m);
+                    m = 0;
+                };
                 for (uint64_t p = lo; p < hi; ++p) {
                     const float x = rp[p];
                     if (x < PHMM_MIN_ACCEPTED_F32) {
                         ++resc;
-                        if (dst) dst[p] = log10(want64 ? r64[p] : 0.0) - PHMM_LOG10_INITIAL_CONSTANT_F64;
+                        mine[m++] = (uint32_t)p;
+                        if (m == 64) flush();
                     }
                     else if (dst) {
                         dst[p] = (double)(log10f(x) - PHMM_LOG10_INITIAL_CONSTANT_F32);
                     }
                 }
+                if (m) flush();
                 n_resc.fetch_add(resc, std::memory_order_relaxed);
             };
             if (n >= (1u << 14))
                 parallel_ranges(n, (c->fin_pool ? c->fin_pool->helpers() : 0u) + 1u, finalize);
             else
                 finalize(0, n, 0);
+        }
+        // pass 2, rare: the fp64 re-run of this chunk's queues (filled by its fp32 kernels, still in the slot's device memory), on the
+        // rescue lane, then the rescued pairs' log10
+        if (!rescued.empty() && dst) {
+            int rc = impl::sweep_rescue(c, rb, &c->rescue_lane);
+            if (rc != PHMM_OK) return rc;
+            if (!direct)
+                HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(st) + off64, rb->raw64.p, n * sizeof(double), hipMemcpyDeviceToHost, c->rescue_lane.stream));
+            HIP_TRY(hipStreamSynchronize(c->rescue_lane.stream));
+            for (uint32_t p : rescued) dst[p] = log10(r64[p]) - PHMM_LOG10_INITIAL_CONSTANT_F64;
         }
         rb->last_rescued = (uint32_t)n_resc.load();
         total.cells += rb->cells;
@@ -258,6 +282,7 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
     try {
         collector = std::thread([&] {
         (void)hipSetDevice(c->device);
+        phmm_detail::HookScope hooks;
         phmm_detail::PoolScope pool(c->fin_pool);
         for (size_t k = 0; k < n_chunks; ++k) {
             {
@@ -531,7 +556,7 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
             HIP_TRY(hipEventRecord(c->chunk_up[slot], up));
             HIP_TRY(hipStreamWaitEvent(c->stream, c->chunk_up[slot], 0));
         }
-        rc = impl::phmm_sweep(c, rb);
+        rc = impl::sweep_fp32(c, rb);  // (the fp64 re-run: the collector's business, see collect)
         if (rc != PHMM_OK) return rc;
         PHASE(4);
         if (direct) {

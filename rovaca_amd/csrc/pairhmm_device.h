@@ -14,6 +14,7 @@ constexpr int kLanesPerPair = 16;     // one DPP row per (read, haplotype) pair;
 constexpr int kBlockThreads = PHMM_BLOCK_THREADS;    // 4 waves = 16 pairs per workgroup
 constexpr int kMaxRowsPerLane = 16;   // K: reads up to 16 * 16 = 256 rows take the single-pass kernel
 constexpr int kMaxRowsPerLaneWide = 8;  // the one-pair-per-wave shape goes further: 64 * 8 = 512 rows in one pass
+constexpr int kMaxRowsPerLaneMid = 8;   // two pairs per wave (32 lanes each): reads up to 32 * 8 = 256 rows, as the 16-lane shape
 constexpr int kPlanes = 6;            // haplotype match planes: read symbol A, C, G, T, N, other
 #ifndef PHMM_STRIPED_ROWS_F32
 #define PHMM_STRIPED_ROWS_F32 8
@@ -87,6 +88,7 @@ struct RaggedSeg
     uint32_t rows;       // rows per lane of the class's sweep
     uint32_t queue;      // its rescue queue (index into rescue_count) ...
     uint32_t list_base;  // ... and where that queue's list begins in rescue_list
+    uint32_t lanes;      // lanes per pair of the class's sweep (the uniform-budget kernel: 16 or 32; the K-range kernels: not read)
 };
 struct RaggedArgs
 {
@@ -97,6 +99,11 @@ struct RaggedArgs
 int ragged_range_of(int rows_per_lane, int lanes_per_pair, bool uniform_gop);
 // uniform gap-continuation penalty and deletion == insertion gap-opens are required (the Rovaca case); uniform_gop as in launch_systolic_f32
 hipError_t launch_systolic_ragged_f32(int lanes_per_pair, bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
+// The uniform-budget form: ONE kernel at four waves per SIMD for every class of the launch; a class whose 16-lane sweep needs more than
+// 128 registers is given as 32 lanes per pair (RaggedSeg::lanes / rows = ceil(R / 32)).  ragged_uniform_lanes_of: which, by the class's
+// 16-lane rows per lane.
+int ragged_uniform_lanes_of(int rows_per_lane_16, bool uniform_gop);
+hipError_t launch_systolic_ragged_uniform_f32(bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
 // striped ("team") kernels: a workgroup of waves_per_team waves (1, 4 or 8) sweeps four pairs; lds_words_per_group is
 // kPlanes * planes_words(longest haplotype of the launch); carry holds 3 * carry_stride values per (team, wave, group).
 // lanes_per_pair: 16 (four pairs per wave) or 64 (one pair per wave)

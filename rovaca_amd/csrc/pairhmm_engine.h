@@ -141,7 +141,7 @@ struct phmm_context
     {
         hipStream_t stream = nullptr, side[kSideStreams] = {nullptr, nullptr, nullptr};
         hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr}, done = nullptr;
-    } lane2;
+    } lane2, rescue_lane;  // rescue_lane: where the chunk pipeline's collector re-runs a chunk's underflowed pairs
     phmm_detail::HostPool *pack_pool = nullptr, *fin_pool = nullptr;  // helper threads of the two sides of that pipeline
     phmm_detail::HostPool *prep_pool = nullptr;  // its prepare workers: chunks k + 1, k + 2, ... are packed and binned while chunk k is enqueued
     phmm_detail::BinScratch prep_scratch[8];     // one binning scratch per prepare worker
@@ -349,7 +349,7 @@ namespace impl
 {
 // pairhmm_capi.cpp: one pass over a resident batch, enqueued on the context's stream set; the CPU backend's two steps
 int sweep_fp32(phmm_context *c, phmm_resident *rb);
-int sweep_rescue(phmm_context *c, phmm_resident *rb);
+int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLane *on = nullptr);
 int cpu_upload(phmm_context *c, const phmm_batch *b, phmm_resident *rb);
 int cpu_sweep(phmm_context *c, phmm_resident *rb);
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats);

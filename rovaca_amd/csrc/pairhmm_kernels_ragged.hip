@@ -59,6 +59,79 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), (ragged_min_waves
     ragged_dispatch<T, MODE, G, KLO, KHI>(sg.rows, a, b - sg.wg_first, sg);
 }
 
+// ----------------------------------------------------------------------------------------------------
+// One register budget for every class: the ragged kernel of chunk- and stage-sized launches.
+//
+// The K ranges above run side by side as two or three kernels with budgets of 128, 168 and 200+ VGPRs.  In a launch of a million pairs
+// that costs nothing: the big-K kernels are launched first, finish in the first third of the pass, and the small-K kernel has the chip
+// to itself for the rest.  In the chunks of a one-shot call (or a stage) the mix never ends -- two chunks are always in flight -- and a
+// SIMD that holds one 168-register wave has room for two more waves, not three: the small-K waves, three quarters of the work, spend
+// the pass at three waves per SIMD instead of four (config 3's one-shot call, round 4: every chunk 16 % slower than the resident
+// rate, 10.1 ms of device time for 7.9 ms of sweeps; config 2, one class and one kernel per chunk, loses nothing).  Here the classes
+// whose 16-lane sweep needs more than 128 registers (reads of 193-256 bases; from 177 with per-base gap-opens) take the 32-lane shape
+// instead -- two pairs per wave, 6-8 rows per lane, about 100 registers -- so that ONE kernel at four waves per SIMD holds every class.
+// Those classes issue about 1.16x the instructions; everything else is the sweep it always was.  Same bits either way.
+// ----------------------------------------------------------------------------------------------------
+template <typename T, int MODE, int K, int KHI>
+__device__ __forceinline__ void ragged_dispatch32(uint32_t rows, const KernelArgs &a, uint32_t wg, const RaggedSeg &sg)
+{
+    if (rows == (uint32_t)K) {
+        if constexpr (MODE == 2)
+            systolic_ugo_sweep<T, K, 32, kBlockThreads>(a, wg, sg.pos_first, sg.count, a.rescue_list + sg.list_base, a.rescue_count + sg.queue);
+        else
+            systolic_sweep<T, K, true, 32, kBlockThreads>(a, wg, sg.pos_first, sg.count, a.rescue_list + sg.list_base, a.rescue_count + sg.queue);
+        return;
+    }
+    if constexpr (K < KHI) ragged_dispatch32<T, MODE, K + 1, KHI>(rows, a, wg, sg);
+}
+
+// the largest rows per lane the 16-lane sweep runs at four waves per SIMD, and the rows per lane of the 32-lane classes above it
+template <int MODE> constexpr int uniform_k16_max() { return MODE == 2 ? 12 : 11; }
+template <int MODE> constexpr int uniform_k32_min() { return (16 * uniform_k16_max<MODE>() + 1 + 31) / 32; }
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kBlockThreads, 4) pairhmm_systolic_ragged_uniform_kernel(KernelArgs a, RaggedArgs m)
+{
+    const uint32_t b = xcd_local_workgroup(blockIdx.x, a.xcd_run_log2);
+    if (b >= m.n_wg) return;
+    uint32_t s = 0;
+    for (uint32_t i = 1; i < m.n_seg; ++i)
+        if (b >= m.seg[i].wg_first) s = i;
+    const RaggedSeg sg = m.seg[s];
+    if (sg.lanes == 32u)
+        ragged_dispatch32<T, MODE, uniform_k32_min<MODE>(), kMaxRowsPerLaneMid>(sg.rows, a, b - sg.wg_first, sg);
+    else
+        ragged_dispatch<T, MODE, 16, 1, uniform_k16_max<MODE>()>(sg.rows, a, b - sg.wg_first, sg);
+}
+
+int ragged_uniform_lanes_of(int rows_per_lane_16, bool uniform_gop)
+{
+    return rows_per_lane_16 <= (uniform_gop ? uniform_k16_max<2>() : uniform_k16_max<1>()) ? 16 : 32;
+}
+
+hipError_t launch_systolic_ragged_uniform_f32(bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s)
+{
+    if (m.n_seg == 0 || m.n_wg == 0) return hipSuccess;
+    if (m.n_seg > (uint32_t)kRaggedMaxSegs) return hipErrorInvalidValue;
+    for (uint32_t i = 0; i < m.n_seg; ++i) {
+        const RaggedSeg &g = m.seg[i];
+        const int k16 = uniform_gop ? uniform_k16_max<2>() : uniform_k16_max<1>(), k32 = uniform_gop ? uniform_k32_min<2>() : uniform_k32_min<1>();
+        const bool ok = g.lanes == 16u ? (g.rows >= 1 && g.rows <= (uint32_t)k16) : g.lanes == 32u ? (g.rows >= (uint32_t)k32 && g.rows <= (uint32_t)kMaxRowsPerLaneMid) : false;
+        if (!ok) return hipErrorInvalidValue;
+    }
+    uint32_t blocks = m.n_wg;
+    if (a.xcd_run_log2) {
+        const uint32_t round = 8u << a.xcd_run_log2;
+        blocks = (blocks + round - 1) / round * round;
+    }
+    const size_t shmem = static_cast<size_t>(kBlockThreads / 16) * a.lds_words_per_group * sizeof(uint32_t);
+    if (uniform_gop)
+        hipLaunchKernelGGL((pairhmm_systolic_ragged_uniform_kernel<float, 2>), dim3(blocks), dim3(kBlockThreads), shmem, s, a, m);
+    else
+        hipLaunchKernelGGL((pairhmm_systolic_ragged_uniform_kernel<float, 1>), dim3(blocks), dim3(kBlockThreads), shmem, s, a, m);
+    return hipGetLastError();
+}
+
 template <typename T, int MODE, int G, int KLO, int KHI>
 static hipError_t launch_ragged_one(const KernelArgs &a, const RaggedArgs &m, hipStream_t s)
 {

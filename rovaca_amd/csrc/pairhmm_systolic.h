@@ -49,11 +49,32 @@ __device__ __forceinline__ double dpp_wave_shr1(double old, double src)
     return r.d;
 }
 
+// 32 lanes per pair (two pairs per wave): lanes 1..31 and 33..63 receive lane i-1, lanes 0 and 32 keep `old`.  Two DPP moves:
+// wave_shr:1 on rows 0, 1 and 3 (lane 16 takes lane 15, lane 48 lane 47; row 2 is left alone), then row_shr:1 on row 2, whose
+// first lane -- lane 32, the first of the second pair -- has no source inside the row and keeps what it had.
+__device__ __forceinline__ float dpp_half_shr1(float old, float src)
+{
+    const int r = __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x138, 0xB, 0xF, false);
+    return __int_as_float(__builtin_amdgcn_update_dpp(r, __float_as_int(src), 0x111, 0x4, 0xF, false));
+}
+
+__device__ __forceinline__ double dpp_half_shr1(double old, double src)
+{
+    union { double d; int i[2]; } o, s, r;
+    o.d = old;
+    s.d = src;
+    r.i[0] = __builtin_amdgcn_update_dpp(__builtin_amdgcn_update_dpp(o.i[0], s.i[0], 0x138, 0xB, 0xF, false), s.i[0], 0x111, 0x4, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(__builtin_amdgcn_update_dpp(o.i[1], s.i[1], 0x138, 0xB, 0xF, false), s.i[1], 0x111, 0x4, 0xF, false);
+    return r.d;
+}
+
 template <int G, typename T>
 __device__ __forceinline__ T dpp_shr1(T old, T src)
 {
     if constexpr (G == 64)
         return dpp_wave_shr1(old, src);
+    else if constexpr (G == 32)
+        return dpp_half_shr1(old, src);
     else
         return dpp_row_shr1(old, src);
 }
@@ -100,7 +121,9 @@ struct Rows
 // wins at 4 waves with a few spills outside the steady loop; K = 12..14 run best at 3 waves.
 #define PHMM_MIN_WAVES(T, K, UG) (sizeof(T) == 8 ? 2 : ((UG) && (K) <= 11) ? 4 : ((UG) && (K) <= 14) ? 3 : 1)
 
-// G = lanes per pair.  16: four pairs per wave (DPP row_shr), the throughput shape.  64: one pair per wave (DPP wave_shr) in
+// G = lanes per pair.  16: four pairs per wave (DPP row_shr), the throughput shape.  32: two pairs per wave -- half the rows per lane,
+// so a read of 193-256 bases needs 7-8 rows (about 100 VGPRs) instead of 13-16 (155-200): the shape that lets EVERY length class of a
+// chunk-sized launch run under one 128-register budget (pairhmm_kernels_ragged.hip), at 1.16x the instructions.  64: one pair per wave (DPP wave_shr) in
 // one-wave workgroups, the latency shape for launches with so few pairs that four-per-wave would leave most SIMDs empty (a
 // single region): a quarter of the rows per lane makes the sweep of a pair about twice as short.
 template <int G> constexpr int systolic_block_threads() { return G == 64 ? 64 : kBlockThreads; }
@@ -117,14 +140,14 @@ __device__ __forceinline__ uint32_t xcd_local_workgroup(uint32_t b, uint32_t run
 // ragged kernels (pairhmm_kernels_ragged.hip: a launch holds several classes, every workgroup picks its K).  `wg` is the workgroup's
 // place in the processing order of its class, [pos_first, pos_first + count) the class's range of a.order, and the two rescue pointers
 // the queue of that class.
-template <typename T, int K, bool UG, int G>
+template <typename T, int K, bool UG, int G, int BT = systolic_block_threads<G>()>
 __device__ __forceinline__ void systolic_sweep(const KernelArgs &a, uint32_t wg, uint32_t pos_first, uint32_t count, uint32_t *rescue_list,
                                                uint32_t *rescue_count)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & (uint32_t)(G - 1);                      // lane inside the pair's G-lane array
     const uint32_t grp_in_block = threadIdx.x / (uint32_t)G;                    // 0..15 (G = 16), 0 (G = 64)
-    const uint32_t gidx = wg * (systolic_block_threads<G>() / G) + grp_in_block;
+    const uint32_t gidx = wg * (BT / G) + grp_in_block;  // BT: threads of the workgroup this sweep runs in
     const bool valid = gidx < count;
     const uint32_t pair = a.order[valid ? pos_first + gidx : 0];
     const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
@@ -203,17 +226,13 @@ __device__ __forceinline__ void systolic_sweep(const KernelArgs &a, uint32_t wg,
     // ---- the sweep ----
     const uint32_t Tg = valid ? H + (G - 1) : 0;  // last step of this group
     uint32_t Tmax = Tg;                           // wave-uniform loop bound
-    if (G == 16) {
-        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
-        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
-    }
+    if (G <= 16) Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+    if (G <= 32) Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
     Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
 
     uint32_t Tmin = Tg;  // until here every lane of the wave is busy once the pipeline is full
-    if (G == 16) {
-        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
-        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
-    }
+    if (G <= 16) Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+    if (G <= 32) Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
     Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
 
     uint32_t mask[K];
@@ -332,14 +351,14 @@ __device__ __forceinline__ void systolic_sweep(const KernelArgs &a, uint32_t wg,
 // occupancy targets of this kernel, measured per K (tools/bench_by_k.py): it has 2K - 1 fewer live registers than the general one, so
 // K = 12 still fits four waves (+1 %) and K = 15 three (5 670 -> 6 050 GCUPS); K = 16 at three waves spills inside the loop (4 980)
 #define PHMM_UGO_MIN_WAVES(T, K) (sizeof(T) == 8 ? 2 : (K) <= 12 ? 4 : (K) <= 15 ? 3 : 1)
-template <typename T, int K, int G>
+template <typename T, int K, int G, int BT = systolic_block_threads<G>()>
 __device__ __forceinline__ void systolic_ugo_sweep(const KernelArgs &a, uint32_t wg, uint32_t pos_first, uint32_t count, uint32_t *rescue_list,
                                                    uint32_t *rescue_count)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & (uint32_t)(G - 1);                      // lane inside the pair's G-lane array
     const uint32_t grp_in_block = threadIdx.x / (uint32_t)G;                    // 0..15 (G = 16), 0 (G = 64)
-    const uint32_t gidx = wg * (systolic_block_threads<G>() / G) + grp_in_block;
+    const uint32_t gidx = wg * (BT / G) + grp_in_block;  // BT: threads of the workgroup this sweep runs in
     const bool valid = gidx < count;
     const uint32_t pair = a.order[valid ? pos_first + gidx : 0];
     const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
@@ -409,17 +428,13 @@ __device__ __forceinline__ void systolic_ugo_sweep(const KernelArgs &a, uint32_t
     // ---- the sweep ----
     const uint32_t Tg = valid ? H + (G - 1) : 0;  // last step of this group
     uint32_t Tmax = Tg;                           // wave-uniform loop bound
-    if (G == 16) {
-        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
-        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
-    }
+    if (G <= 16) Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+    if (G <= 32) Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
     Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
 
     uint32_t Tmin = Tg;  // until here every lane of the wave is busy once the pipeline is full
-    if (G == 16) {
-        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
-        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
-    }
+    if (G <= 16) Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+    if (G <= 32) Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
     Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
 
     uint32_t mask[K];

@@ -79,3 +79,11 @@ def test_device_line_carries_the_measured_traffic():
     d = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-adapter")
     assert d["roofline"]["traffic"] and d["roofline"]["traffic"] < d["roofline"]["algorithmic_bytes"]  # reads shared 25x / 40x inside the L2s
     assert 0.5 < d["roofline_issue"]["frac"] <= 1.0
+    # the other configs ride on the default line, each checked against the CPU leg on a sample
+    cfg = d["configs"]
+    assert "error" not in cfg, cfg
+    c3, c5, sw = cfg["c3"], cfg["c5"], cfg["sw"]
+    assert c3["value_resident"] > 0 and c3["value_e2e"] > 0 and c3["pairs"] == 1000000 and 1 <= c3["launches_per_pass"] <= 4
+    assert c3["bit_identical_to_cpu_sample"] is True and c3["e2e_identical_to_resident_path"] is True
+    assert c5["value"] > 0 and c5["fp64_ms"] > 0 and c5["rescued_pairs"] == c5["pairs"] == 1000 and c5["identical_to_cpu_sample"] is True
+    assert sw["value"] > 0 and "bit-identical" in sw["parity_sample"]

@@ -19,11 +19,15 @@ TOL_RESCUE = 1e-9  # fp64 vs scalar double oracle, same operation order
 # "ragged": the classes share launches, every workgroup picks its K (pairhmm_kernels_ragged.hip; the default for Rovaca-case batches);
 # "ride-along": one launch per class, small classes handed to the next class up (PHMM_NO_RAGGED; the default until round 3, and still
 # the plan of batches with general per-base gap penalties); "per-class": one launch per class, nothing merged.
-LAUNCH_PLANS = ("ragged", "ride-along", "per-class")
+# "ragged-ranges": the ragged form of launches of 2^18 pairs or more -- one kernel per range of K that shares a register budget -- forced
+# onto small batches (the default below that size is the uniform-budget kernel: one launch, big-K classes as 32 lanes per pair).
+LAUNCH_PLANS = ("ragged", "ragged-ranges", "ride-along", "per-class")
 
 
 def _set_launch_plan(monkeypatch, plan):
-    if plan != "ragged":
+    if plan == "ragged-ranges":
+        monkeypatch.setenv("PHMM_RAGGED_UNIFORM_BELOW", "0")
+    elif plan != "ragged":
         monkeypatch.setenv("PHMM_NO_RAGGED", "1")
     if plan == "per-class":
         monkeypatch.setenv("PHMM_NO_BIN_MERGE", "1")
@@ -503,19 +507,24 @@ def test_ragged_launches_are_the_per_class_launches(engine, lanes, pcr_model, mo
         raw0, l10_0, st0 = engine.compute(b, prep=prep)
         monkeypatch.delenv("PHMM_NO_RAGGED")
         monkeypatch.delenv("PHMM_NO_BIN_MERGE")
-        raw1, l10_1, st1 = engine.compute(b, prep=prep)
+        raw1, l10_1, st1 = engine.compute(b, prep=prep)  # the uniform-budget kernel: one launch (four pairs per wave forced: lanes 16 / 32)
+        monkeypatch.setenv("PHMM_RAGGED_UNIFORM_BELOW", "0")
+        raw4, l10_4, st4 = engine.compute(b, prep=prep)  # one kernel per K range that shares a register budget: up to three
         monkeypatch.setenv("PHMM_XCD_LOCAL_MIN_PAIRS", "1")
         raw2, l10_2, st2 = engine.compute(b, prep=prep)
+        monkeypatch.delenv("PHMM_RAGGED_UNIFORM_BELOW")
+        raw5, l10_5, st5 = engine.compute(b, prep=prep)  # (the XCD-local order on the uniform kernel's grid)
         monkeypatch.delenv("PHMM_XCD_LOCAL_MIN_PAIRS")
         # the fp64 re-run: queues that take the same kernel share a launch (the default) or get one launch each
         monkeypatch.setenv("PHMM_NO_RESCUE_MERGE", "1")
         raw3, l10_3, st3 = engine.compute(b, prep=prep)
         monkeypatch.delenv("PHMM_NO_RESCUE_MERGE")
-        for raw, l10, st in ((raw1, l10_1, st1), (raw2, l10_2, st2), (raw3, l10_3, st3)):
+        for raw, l10, st in ((raw1, l10_1, st1), (raw2, l10_2, st2), (raw3, l10_3, st3), (raw4, l10_4, st4), (raw5, l10_5, st5)):
             assert np.array_equal(raw.view(np.uint32), raw0.view(np.uint32))
             assert np.array_equal(l10, l10_0, equal_nan=True)
             assert int(st.n_rescued) == int(st0.n_rescued) > 0
-        assert int(st1.n_launches) < int(st0.n_launches) and int(st1.n_launches) <= 3
+        assert int(st1.n_launches) == 1 and int(st4.n_launches) <= 3 < int(st0.n_launches)
+        assert int(st4.n_launches) == (1 if lanes == 64 else 3)  # (one pair per wave: every class fits one kernel's budget anyway)
     # and the oracle, on a sample (the batch prepared on the host the same way)
     if pcr_model == 0:
         k = rng.choice(b.n_pairs, 400, replace=False)
