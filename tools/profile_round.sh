@@ -5,22 +5,29 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
 for c in c2 c3 c5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$c -o $c -- python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-adapter > $OUT/bench_$c.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$c -o $c -- python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/bench_$c.log 2>&1
   tail -1 $OUT/bench_$c.log | cut -c1-160
 done
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -o pmc -- python3 bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-adapter > $OUT/pmc_$tag.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -o pmc -- python3 bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/pmc_$tag.log 2>&1
   echo "pmc $grp done"
 done
 # the same batch through the general kernel (per-base gap-opens: what a run under the default PCR model takes)
 export PHMM_ENABLE_TEST_HOOKS=1 PHMM_NO_UNIFORM_GOP=1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcpcr_$tag -o pmc -- python3 bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-adapter > $OUT/pmcpcr_$tag.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcpcr_$tag -o pmc -- python3 bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/pmcpcr_$tag.log 2>&1
   echo "pmc (general kernel) $grp done"
 done
 unset PHMM_NO_UNIFORM_GOP PHMM_ENABLE_TEST_HOOKS
+# configs 3 and 5: instruction counts and traffic per pass (bench.py --config c3 / c5 price their lines with them)
+for c in c3 c5; do
+for grp in "SQ_INSTS_VALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
+  tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc${c}_$tag -o pmc -- python3 bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/pmc${c}_$tag.log 2>&1
+  echo "pmc $c $grp done"
+done; done
 find $OUT -name "*.csv" | head -30
 # Smith-Waterman aligner: kernel trace of bench.py --config sw
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sw -o sw -- python3 bench.py --config sw --no-cpu-baseline > $OUT/bench_sw.log 2>&1

@@ -73,6 +73,29 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         extra = {"c2_pcr": int(2 * mean_pcr["FETCH_SIZE"] * 1024 + mean_pcr["WRITE_SIZE"] * 1024),
                  "c2_pcr_valu_wave_instructions": int(mean_pcr.get("SQ_INSTS_VALU", 0)),
                  "c2_pcr_kernel": (pcr_kernel or "").replace("void ", "").split("(")[0]}
+    # configs 3 and 5: totals per PASS (bench.py --steps 3 --warmup 1 = 4 passes) over every sweep kernel of the pass
+    def per_pass(cfg, name_part, passes=4):
+        tot, names = {}, set()
+        for f in glob.glob(os.path.join(src, "pmc%s_*" % cfg, "pmc_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if name_part in r["Kernel_Name"]:
+                    tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    names.add(r["Kernel_Name"].replace("void ", "").split("(")[0])
+        return {k: v / passes for k, v in tot.items()}, sorted(names)
+
+    c3, c3_names = per_pass("c3", "pairhmm_systolic")
+    if c3.get("SQ_INSTS_VALU"):
+        extra.update({"c3": int(2 * c3.get("FETCH_SIZE", 0) * 1024 + c3.get("WRITE_SIZE", 0) * 1024),
+                      "c3_valu_wave_instructions": int(c3["SQ_INSTS_VALU"]), "c3_waves": int(c3.get("SQ_WAVES", 0)),
+                      "c3_kernel": " + ".join(c3_names)})
+    for prec, part in (("fp32", "pairhmm_band_kernel<float"), ("fp64", "pairhmm_band_kernel<double")):
+        c5, c5_names = per_pass("c5", part)
+        if c5.get("SQ_INSTS_VALU"):
+            extra.update({"c5_%s" % prec: int(2 * c5.get("FETCH_SIZE", 0) * 1024 + c5.get("WRITE_SIZE", 0) * 1024),
+                          "c5_%s_valu_wave_instructions" % prec: int(c5["SQ_INSTS_VALU"]), "c5_%s_waves" % prec: int(c5.get("SQ_WAVES", 0)),
+                          "c5_%s_wave_cycles" % prec: int(c5.get("SQ_WAVE_CYCLES", 0)), "c5_%s_busy_cycles" % prec: int(c5.get("SQ_BUSY_CYCLES", 0)),
+                          "c5_%s_active_inst_valu" % prec: int(c5.get("SQ_ACTIVE_INST_VALU", 0)), "c5_%s_wait_inst_any" % prec: int(c5.get("SQ_WAIT_INST_ANY", 0)),
+                          "c5_%s_kernel" % prec: " + ".join(c5_names)})
     json.dump({"kernel_source_id": kernel_source_id(), **extra, "c2": int(2 * fetch + write),
                "_note": "bytes per launch of %s on config c2: 2 x FETCH_SIZE (gfx950 correction, upper bound) + WRITE_SIZE, "
                         "from profiles/%s_c2_pmc_summary.txt" % (hot["Name"].replace("void ", "").split("(")[0], tag),
