@@ -962,8 +962,39 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
         a.ph2pr = c->ph2pr_f64.p;
         a.mm_table = c->mm_f64.p;
         a.out_raw = rb->out64_host ? static_cast<void *>(rb->out64_host) : static_cast<void *>(rb->raw64.p);
+        // tuning aid: PHMM_BAND_TIMELINE=<file> -- the first 64 teams of the band launch log every stripe (begin, first non-skipped
+        // superstep, end, waits; 100 MHz ticks), dumped as text after a synchronisation.  The A/B behind DESIGN.md's config 5 section.
+        const char *tl_path = L.sh.waves > 1 ? phmm_hook("PHMM_BAND_TIMELINE") : nullptr;
+        DevBuf<unsigned long long> tl;
+        const uint32_t tl_teams = std::min<uint32_t>(64u, L.teams);
+        const size_t tl_n = (size_t)tl_teams * phmm::kTimelineStripes * phmm::kTimelineWords;
+        if (tl_path) {
+            HIP_TRY(tl.alloc(tl_n));
+            HIP_TRY(hipMemsetAsync(tl.p, 0, tl_n * sizeof(unsigned long long), st));
+            a.timeline = tl.p;
+            a.timeline_teams = tl_teams;
+        }
         HIP_TRY(phmm::launch_striped_f64(L.rows, rb->uniform_gcp, L.sh.waves, L.sh.lanes, a, rb->carry64.p + L.carry_at, L.max_hap + 1,
                                          L.teams, st));
+        if (tl_path) {
+            std::vector<unsigned long long> h(tl_n);
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(h.data(), tl.p, tl_n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(tl_path, "w")) {
+                fprintf(f, "# team stripe begin_us first_nonskipped_done_us end_us c_first out_first out_last waited_us supersteps_run (times since the launch's first record)\n");
+                unsigned long long t0 = ~0ull;
+                for (size_t i = 0; i < tl_n; i += phmm::kTimelineWords)
+                    if (h[i + 2]) t0 = std::min(t0, h[i]);
+                for (uint32_t tm = 0; tm < tl_teams; ++tm)
+                    for (int v = 0; v < phmm::kTimelineStripes; ++v) {
+                        const unsigned long long *r = h.data() + ((size_t)tm * phmm::kTimelineStripes + v) * phmm::kTimelineWords;
+                        if (!r[2]) continue;
+                        fprintf(f, "%u %d %.2f %.2f %.2f %llu %lld %llu %.2f %llu\n", tm, v, (r[0] - t0) / 100.0, r[1] ? (r[1] - t0) / 100.0 : -1.0,
+                                (r[2] - t0) / 100.0, r[3], (long long)(int)r[4], r[5], r[6] / 100.0, r[7]);
+                    }
+                fclose(f);
+            }
+        }
     }
     if (fan_out) {
         for (int i = 0; i < c->n_side; ++i) {

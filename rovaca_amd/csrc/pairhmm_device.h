@@ -70,7 +70,12 @@ struct KernelArgs
     uint32_t n_rescue_queues;
     uint32_t rescue_queue[kMaxRescueQueuesPerLaunch];
     uint32_t rescue_base[kMaxRescueQueuesPerLaunch];
+    // tuning aid (PHMM_BAND_TIMELINE): the band kernel's waves log every stripe they sweep -- kTimelineWords 64-bit words per (team,
+    // stripe), the first timeline_teams teams only; null otherwise.  Times are s_memrealtime ticks (100 MHz).
+    unsigned long long *timeline;
+    uint32_t timeline_teams;
 };
+constexpr int kTimelineStripes = 64, kTimelineWords = 8;
 
 // lanes_per_pair 16: rows_per_lane = ceil(R / 16) in 1..kMaxRowsPerLane; 64: ceil(R / 64) in 1..kMaxRowsPerLaneWide
 // uniform_gop (only with uniform_gcp): every base of the batch has the same gap-open quality too -> the variant that shares p_mm / p_mx

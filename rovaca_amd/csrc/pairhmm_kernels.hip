@@ -40,20 +40,41 @@ namespace phmm
 {
 
 // ----------------------------------------------------------------------------------------------------
-// the single-pass systolic kernels, one launch per rows-per-lane class: the sweep itself is pairhmm_systolic.h
+// the single-pass systolic kernels, one launch per rows-per-lane class: the sweep itself is the text of pairhmm_systolic_sweep.inc /
+// pairhmm_systolic_ugo_sweep.inc (shared with the ragged kernels' sweep functions, pairhmm_systolic.h)
 // ----------------------------------------------------------------------------------------------------
 template <typename T, int K, bool UG, int G>
 __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHMM_MIN_WAVES(T, K, UG))
     pairhmm_systolic_kernel(KernelArgs a)
 {
-    systolic_sweep<T, K, UG, G>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count);
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (uint32_t)(G - 1);                      // lane inside the pair's G-lane array
+    const uint32_t grp_in_block = threadIdx.x / (uint32_t)G;                    // 0..15 (G = 16), 0 (G = 64)
+    const uint32_t gidx = xcd_local_workgroup(blockIdx.x, a.xcd_run_log2) * (systolic_block_threads<G>() / G) + grp_in_block;
+    const bool valid = gidx < a.n_pairs;
+    const uint32_t pair = a.order[valid ? gidx : 0];
+#define PHMM_SWEEP_RESCUE_LIST a.rescue_list
+#define PHMM_SWEEP_RESCUE_COUNT a.rescue_count
+#include "pairhmm_systolic_sweep.inc"
+#undef PHMM_SWEEP_RESCUE_LIST
+#undef PHMM_SWEEP_RESCUE_COUNT
 }
 
 template <typename T, int K, int G>
 __global__ void __launch_bounds__(systolic_block_threads<G>(), G == 64 ? 4 : PHMM_UGO_MIN_WAVES(T, K))
     pairhmm_systolic_ugo_kernel(KernelArgs a)
 {
-    systolic_ugo_sweep<T, K, G>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count);
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & (uint32_t)(G - 1);                      // lane inside the pair's G-lane array
+    const uint32_t grp_in_block = threadIdx.x / (uint32_t)G;                    // 0..15 (G = 16), 0 (G = 64)
+    const uint32_t gidx = xcd_local_workgroup(blockIdx.x, a.xcd_run_log2) * (systolic_block_threads<G>() / G) + grp_in_block;
+    const bool valid = gidx < a.n_pairs;
+    const uint32_t pair = a.order[valid ? gidx : 0];
+#define PHMM_SWEEP_RESCUE_LIST a.rescue_list
+#define PHMM_SWEEP_RESCUE_COUNT a.rescue_count
+#include "pairhmm_systolic_ugo_sweep.inc"
+#undef PHMM_SWEEP_RESCUE_LIST
+#undef PHMM_SWEEP_RESCUE_COUNT
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -497,6 +518,9 @@ template <int G> __device__ __forceinline__ uint32_t team_last_block(uint32_t l)
 #ifndef PHMM_BAND_ROW_BARRIER
 #define PHMM_BAND_ROW_BARRIER 0
 #endif
+#ifndef PHMM_BAND_PREFETCH_BLOCKS
+#define PHMM_BAND_PREFETCH_BLOCKS 2  // 1: the shorter hand-over lag tried in round 4 (tools/build_variant.sh for the A/B): no gain, see kPrefetch
+#endif
 template <typename T, int K, bool UG, int WP, int G>
 __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 : PHMM_TEAM_WAVES_F64) pairhmm_band_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
 {
@@ -505,6 +529,15 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
     constexpr uint32_t kGroups = 64 / G;  // pairs per wave
     constexpr uint32_t kRing = 64;        // columns parked per value: two blocks of 32
     constexpr uint32_t kLag = team_lag<G>();
+    // How far ahead of the block a superstep consumes its carry loads are issued.  Two blocks (load block c + 2, park block c + 1,
+    // consume block c) hide the L2 round trip twice over, and every block of look-ahead is a superstep of lag between consecutive
+    // stripes of a pair.  Round 4 measured the chain on one 10 000 x 12 000 pair (tools/band_timeline.py, profiles/r4_band_timeline_*):
+    // consecutive stripes of the band begin 12.9 supersteps apart -- 8.4 because the band moves that far per 256 rows, 4.5 of hand-over
+    // -- and tried one block of look-ahead (= 1: loads issued when the superstep begins, parked half way through it, two blocks only
+    // when the stripe above is far ahead): the stripes then begin 12.8 supersteps apart, but the superstep itself got 11 % slower
+    // (5.64 -> 6.25 us; the loop with the mid-way park allocates worse: 251 registers against 237) and config 5 went 12.4 -> 13.3 ms.
+    // Kept as a build variant, not the default.
+    constexpr uint32_t kPrefetch = PHMM_BAND_PREFETCH_BLOCKS;
     const uint32_t lane = threadIdx.x & (G - 1);
     const uint32_t grp = (threadIdx.x & 63u) / G;
     const uint32_t wave = threadIdx.x >> 6;
@@ -757,13 +790,18 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 sumX = 0;
             }
         };
-        // carry ring at the first superstep c0 of a stripe: blocks c0 and c0 + 1 parked, block c0 + 2 in flight
+        // carry ring at the first superstep c0 of a stripe: block c0 parked, block c0 + 1 in flight (PHMM_BAND_PREFETCH_BLOCKS = 1), or
+        // blocks c0 and c0 + 1 parked and block c0 + 2 in flight (= 2, the form until round 3)
+        bool inflight = false;  // kPrefetch == 1: the block after the one being consumed is already in the pre-registers
         auto ring_init = [&](uint32_t c0) {
             carry_load(c0);
             carry_park(c0);
-            carry_load(c0 + 1);
-            carry_park(c0 + 1);
-            carry_load(c0 + 2);
+            if (kPrefetch == 2u) {
+                carry_load(c0 + 1);
+                carry_park(c0 + 1);
+                carry_load(c0 + 2);
+            }
+            inflight = false;
             ring_fetch(32u * c0 + 1u);
             curM = nxtM;
             curX = nxtX;
@@ -808,10 +846,12 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 *reinterpret_cast<V3 *>(wbase + (j * kGroups + grp) * 3u) = V3{M[K - 1], X[K - 1], Y[K - 1]};
             }
         };
-        // 32 steps with every lane of the wave busy: no per-lane predicate, the two register sets swap roles without a move
-        auto superstep_full = [&](uint32_t t0, auto is_last) {
+        // 32 steps with every lane of the wave busy: no per-lane predicate, the two register sets swap roles without a move; `mid` runs
+        // once, half way (the late park of the next carry block)
+        auto superstep_full = [&](uint32_t t0, auto is_last, auto &&mid) {
 #pragma unroll 1
             for (uint32_t t = t0; t < t0 + 32u; t += 2) {
+                if (t == t0 + 16u) mid();
                 ring_fetch(t + 1);
                 step(t, aM, aX, aY, bM, bX, bY, is_last);
                 curM = nxtM;
@@ -826,14 +866,33 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
         };
 
         // one superstep (32 columns) of stripe v; returns true when it was skipped as all-zero
-        auto superstep = [&](uint32_t v, uint32_t c, uint32_t c_first) -> bool {
-            if (c == c_first) {
-                ring_init(c);
+        // far: the stripe above has block c + 2 complete as well (it is finished, or far enough ahead) -- then that block is loaded a
+        // whole superstep before it is parked, as until round 3: a stripe that walks behind a finished one (the rows under the top
+        // strip, the skipped supersteps at a band's edges) does not pay an L2 round trip per superstep.  A stripe that follows its
+        // producer at the minimum distance -- the steady walk of the band -- never sees `far` and keeps the short lag.
+        auto superstep = [&](uint32_t v, uint32_t c, uint32_t c_first, bool far) -> bool {
+            bool park_late = false;  // block c + 1 is parked half way through this superstep (it is being loaded now)
+            if (c == c_first) ring_init(c);
+            if (kPrefetch == 2u) {
+                if (c != c_first) {
+                    carry_park(c + 1);  // block c + 1 joins the ring (block c was parked one superstep ago)
+                    carry_load(c + 2);
+                }
+            }
+            else if (inflight) {
+                carry_park(c + 1);  // loaded during the last superstep
+                inflight = far;
+                if (far) carry_load(c + 2);
             }
             else {
-                carry_park(c + 1);  // block c + 1 joins the ring (block c was parked one superstep ago)
-                carry_load(c + 2);
+                carry_load(c + 1);
+                park_late = true;
             }
+            auto late_park = [&]() {
+                carry_park(c + 1);
+                inflight = far;
+                if (far) carry_load(c + 2);
+            };
             const uint32_t t0 = 32u * c + 1u;
             const uint32_t t1 = min(t0 + 31u, Tmax);
             uint32_t Tmin = Tg;  // wave-uniform: the last step at which every group of the wave is still sweeping
@@ -861,6 +920,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                         if (t > (uint32_t)(G - 1)) *reinterpret_cast<V3 *>(wbase + ((t - (G - 1)) * kGroups + grp) * 3u) = V3{0, 0, 0};
                     }
                 }
+                if (park_late) late_park();  // (waits for the load: a stripe this close behind its producer is waiting for it anyway)
                 ring_fetch(t1 + 1);
                 curM = nxtM;
                 curX = nxtX;
@@ -870,13 +930,21 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 masks_reload(t0);
                 if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
                     // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
+                    auto mid = [&]() {
+                        if (park_late) late_park();  // its loads were issued 16 steps (3 us) ago; the last step of this superstep already
+                    };                               // fetches the block's first column
                     if (v + 1 == max_stripes)
-                        superstep_full(t0, std::true_type{});
+                        superstep_full(t0, std::true_type{}, mid);
                     else
-                        superstep_full(t0, std::false_type{});
+                        superstep_full(t0, std::false_type{}, mid);
                 }
                 else {
+                    bool parked = !park_late;
                     for (uint32_t t = t0; t <= t1; ++t) {
+                        if (!parked && t == t0 + 16u) {
+                            late_park();
+                            parked = true;
+                        }
                         ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
                         if ((t > lane) && (t <= Tg)) {
                             if (t & 1u)
@@ -888,6 +956,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                         curX = nxtX;
                         curY = nxtY;
                     }
+                    if (!parked) late_park();  // (a row that ends inside the first half of its last superstep)
                 }
             }
             return skipped;
@@ -914,13 +983,18 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             // the chain of stripes cannot dead-lock; every wait is bounded all the same (a stuck team poisons its results
             // instead of hanging the device).  No barrier inside the sweep.
             constexpr uint32_t kUnknown = 0xFFFFFFFFu;
-            constexpr uint32_t kNeed = G == 64 ? 5u : 4u;  // block b of a stripe is complete once superstep b + 2 (G = 64) / b + 1 is done
+            // block b of a stripe is complete once its superstep b + 2 (G = 64) / b + 1 (G = 16) is done, and a superstep begins by loading
+            // the block kPrefetch ahead of the one it consumes
+            constexpr uint32_t kNeed = (G == 64 ? 3u : 2u) + kPrefetch;
             auto rec_of = [&](uint32_t round, uint32_t w) { return team_rec + ((round & 1u) * WP + w) * 8u; };
             auto ld = [&](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
             auto st = [&](uint32_t *p, uint32_t x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
             bool stuck = false;
+            const bool log = a.timeline != nullptr && team < a.timeline_teams;  // tuning aid: see KernelArgs::timeline
+            unsigned long long waited = 0;
             auto wait_for = [&](auto &&ready) {
                 uint32_t spins = 0;
+                const unsigned long long w0 = log ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 while (!stuck && !ready()) {
                     __builtin_amdgcn_s_sleep(4);
                     if (++spins > (1u << 22)) {  // seconds: never reached unless the protocol is broken
@@ -928,9 +1002,14 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                         break;
                     }
                 }
+                if (log) waited += __builtin_amdgcn_s_memrealtime() - w0;
             };
             for (uint32_t round = 0; round * WP + uwave < max_stripes; ++round) {
                 const uint32_t v = round * WP + uwave;
+                const unsigned long long t_begin = log ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                unsigned long long t_first = 0;
+                uint32_t n_run = 0;
+                waited = 0;
                 stripe_setup(v);
                 const bool whole_row = a.no_early_exit || __ballot(first && Tg != 0) != 0;  // (test hook: sweep everything)
                 const uint32_t *prec = v > 0 ? rec_of(uwave == 0 ? round - 1 : round, (uwave + WP - 1) % WP) : nullptr;
@@ -976,7 +1055,13 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
-                    const bool skipped = superstep(v, c, c_first);
+                    // (block c + 2 of the stripe above is complete once its superstep c + 4 (G = 64) / c + 3 is)
+                    const bool far = kPrefetch == 2u || prod_done || ld(prec + 1) >= c + kNeed + 1u;
+                    const bool skipped = superstep(v, c, c_first, far);
+                    if (log && !skipped) {
+                        if (n_run == 0) t_first = __builtin_amdgcn_s_memrealtime();  // (after the first non-skipped superstep)
+                        ++n_run;
+                    }
                     if (!skipped) {
                         if (out_first == kUnknown) {
                             out_first = c;
@@ -1001,6 +1086,17 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 if (v + 1 == max_stripes) {
                     if (stuck) sumM = sumM / static_cast<T>(0) - sumM / static_cast<T>(0);  // NaN: never silently wrong
                     write_result();
+                }
+                if (log && lane == 0 && v < (uint32_t)kTimelineStripes) {
+                    unsigned long long *r = a.timeline + (static_cast<size_t>(team) * kTimelineStripes + v) * kTimelineWords;
+                    r[0] = t_begin;
+                    r[1] = t_first;
+                    r[2] = __builtin_amdgcn_s_memrealtime();
+                    r[3] = c_first;
+                    r[4] = out_first;
+                    r[5] = out_last;
+                    r[6] = waited;
+                    r[7] = n_run;
                 }
             }
             (void)n_super;

@@ -150,193 +150,11 @@ __device__ __forceinline__ void systolic_sweep(const KernelArgs &a, uint32_t wg,
     const uint32_t gidx = wg * (BT / G) + grp_in_block;  // BT: threads of the workgroup this sweep runs in
     const bool valid = gidx < count;
     const uint32_t pair = a.order[valid ? pos_first + gidx : 0];
-    const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
-    const uint32_t R = a.read_len[r], H = a.hap_len[h];
-    const uint32_t roff = a.read_off[r];
-    const uint32_t W = planes_words(H);
-    const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
-    const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
-
-    // ---- stage this pair's haplotype planes into LDS (kPlanes * W words, 16 lanes copy) ----
-    uint32_t *pl = lds + grp_in_block * a.lds_words_per_group;
-    {
-        const uint32_t *src = a.planes + a.plane_off[h];
-        for (uint32_t i = lane; i < kPlanes * W; i += G) pl[i] = src[i];
-    }
-
-    // ---- per-row constants (pairhmm_internal.cpp:466-480 == core/avx512_s.cpp:90-101) ----
-    Rows<T, K, UG> P;
-    T M[K], X[K], Y[K];
-    uint32_t cls_lo = 0, cls_hi = 0;  // 3-bit plane class per row, packed (K <= 16 -> 48 bits)
-    const T init_y = Num<T>::init_const() / static_cast<T>(H);  // rovaca/avx_512_float.cc:32
-    const int pad = G * K - static_cast<int>(R);                  // rows [0, pad) are boundary replicas
-    if (UG) {
-        uint32_t c0 = a.read_gcp[roff] & 127u;
-        P.p_gapm_r[0] = static_cast<T>(1.0) - ph2pr[c0];
-        P.p_xx_r[0] = ph2pr[c0];
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int row = static_cast<int>(lane) * K + k - pad;
-        uint32_t cls = 5;
-        if (row >= 0) {
-            const uint32_t at = roff + static_cast<uint32_t>(row);
-            const uint32_t _i = a.read_ins[at] & 127u, _d = a.read_del[at] & 127u, _c = a.read_gcp[at] & 127u,
-                           _q = a.read_qual[at] & 127u;
-            const uint32_t mx = _i > _d ? _i : _d, mn = _i > _d ? _d : _i;
-            P.p_mm[k] = mmtab[((mx * (mx + 1)) >> 1) + mn];  // core/context.h:162-173
-            P.p_mx[k] = ph2pr[_i];
-            if (!UG) P.p_my_r[UG ? 0 : k] = ph2pr[_d];
-            P.p_yy[k] = ph2pr[_c];
-            if (!UG) {
-                P.p_gapm_r[UG ? 0 : k] = static_cast<T>(1.0) - ph2pr[_c];
-                P.p_xx_r[UG ? 0 : k] = ph2pr[_c];
-            }
-            const T dist = ph2pr[_q];
-            P.hi[k] = static_cast<T>(1.0) - dist;
-            P.lo[k] = Num<T>::div3(dist);
-            cls = read_class(a.read_bases[at]);
-            M[k] = 0;
-            X[k] = 0;
-            Y[k] = 0;
-        }
-        else {
-            // boundary replica: M = X = 0 and Y = init at every column (prior 0 kills M, p_yy = 1 holds Y)
-            P.p_mm[k] = 0;
-            P.p_mx[k] = 0;
-            if (!UG) P.p_my_r[UG ? 0 : k] = 0;
-            P.p_yy[k] = 1;
-            if (!UG) {
-                P.p_gapm_r[UG ? 0 : k] = 0;
-                P.p_xx_r[UG ? 0 : k] = 0;
-            }
-            P.hi[k] = 0;
-            P.lo[k] = 0;
-            M[k] = 0;
-            X[k] = 0;
-            Y[k] = init_y;
-        }
-        if (k < 10)
-            cls_lo |= cls << (3 * k);
-        else
-            cls_hi |= cls << (3 * (k - 10));
-    }
-    __syncthreads();  // planes visible (each group only reads its own, but keep the block-wide fence simple)
-
-    // ---- the sweep ----
-    const uint32_t Tg = valid ? H + (G - 1) : 0;  // last step of this group
-    uint32_t Tmax = Tg;                           // wave-uniform loop bound
-    if (G <= 16) Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
-    if (G <= 32) Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
-    Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
-
-    uint32_t Tmin = Tg;  // until here every lane of the wave is busy once the pipeline is full
-    if (G <= 16) Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
-    if (G <= 32) Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
-    Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
-
-    uint32_t mask[K];
-    // The row above slot 0 travels between lanes in two register sets that swap roles every step: one holds that
-    // row at the current column (written by the DPP shift of this step), the other at the previous column (written
-    // one step earlier).  Lane 0 never receives anything, so its copies keep the boundary row (0, 0, init) for ever;
-    // the DPP's `old` operand is the destination itself, which costs no instruction.  Before a lane's first step
-    // both sets hold column 0 of the row above: Y[0][0] = init when that row is the boundary row or a replica of it
-    // (lane * K <= pad), and 0 when it is a read row (M[i][0] = X[i][0] = Y[i][0] = 0).
-    const T y_col0 = (static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
-    T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
-    T sumM = 0, sumX = 0;
-    const uint32_t wmax = W - 2;
-
-    auto reload = [&](uint32_t t) {
-        // every row's 32-column window of its match plane, starting at this lane's next column
-        const uint32_t jn = t > lane ? t - lane : 1u;  // 1-based
-        uint32_t w = (jn - 1) >> 5;
-        const uint32_t s = (jn - 1) & 31u;
-        w = w < wmax ? w : wmax;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
-            const uint32_t *p = pl + cls * W + w;
-            const uint32_t w0 = p[0], w1 = p[1];
-            mask[k] = (w0 << s) | ((w1 >> 1) >> (31u - s));  // bits [s, s+32) of w0:w1, MSB first (s = 0..31)
-        }
-    };
-
-    // one anti-diagonal.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it at this column.
-    auto step = [&](T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
-        uM0 = dpp_shr1<G>(uM0, M[K - 1]);
-        uX0 = dpp_shr1<G>(uX0, X[K - 1]);
-        uY0 = dpp_shr1<G>(uY0, Y[K - 1]);
-        // Pass 1, bottom row first: Y' and M' read only the previous anti-diagonal, so walking upwards lets every
-        // value be overwritten in place (row k's old M/X/Y are last read by row k+1, which is already done).
-#pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
-            uint32_t nm;
-            const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
-            mask[k] = nm;
-            const T prior = hit ? P.hi[k] : P.lo[k];
-            Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my(k));
-            const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
-            T tt = gM * P.p_mm[k];
-            tt = Num<T>::fma_(gX, P.p_gapm(k), tt);
-            tt = Num<T>::fma_(gY, P.p_gapm(k), tt);
-            M[k] = tt * prior;
-            // Keep the rows in program order: measured on MI355X, hipcc's own interleavings of this block run 5-25 %
-            // slower (tools/try_variants.sh), whatever the scheduling strategy.
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // Pass 2, top row first: the insertion state chains down the column through the NEW M and X.
-        T uM = uM0, uX = uX0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            X[k] = Num<T>::fma_(uX, P.p_xx(k), uM * P.p_mx[k]);
-            uM = M[k];
-            uX = X[k];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
-        sumX = sumX + X[K - 1];
-    };
-    auto step_t = [&](uint32_t t) {
-        if (t & 1u)
-            step(aM, aX, aY, bM, bX, bY);
-        else
-            step(bM, bX, bY, aM, aX, aY);
-    };
-
-    uint32_t t = 1;
-    // fill: lane l starts at step l + 1
-    const uint32_t Tfill = Tmax < (uint32_t)(G - 1) ? Tmax : (uint32_t)(G - 1);
-    for (; t <= Tfill; ++t) {
-        if ((t & 31u) == 1u) reload(t);
-        if ((t > lane) && (t <= Tg)) step_t(t);
-    }
-    // steady state: every lane of all four pairs has work, no per-lane predicate
-    if (t <= Tmin && !(t & 1u)) {
-        step(bM, bX, bY, aM, aX, aY);
-        ++t;
-    }
-    for (; t + 1 <= Tmin; t += 2) {  // t is odd here: the two register sets swap roles without a single move
-        if ((t & 31u) == 1u) reload(t);
-        step(aM, aX, aY, bM, bX, bY);
-        step(bM, bX, bY, aM, aX, aY);
-    }
-    if (t <= Tmin) {
-        if ((t & 31u) == 1u) reload(t);
-        step(aM, aX, aY, bM, bX, bY);
-        ++t;
-    }
-    // drain: pairs with a shorter haplotype than the longest of the wave drop out group by group
-    for (; t <= Tmax; ++t) {
-        if ((t & 31u) == 1u) reload(t);
-        if (t <= Tg) step_t(t);
-    }
-    if (valid && lane == G - 1) {
-        const T res = sumM + sumX;
-        reinterpret_cast<T *>(a.out_raw)[pair] = res;
-        if (sizeof(T) == 4 && rescue_list && res < static_cast<T>(1e-28f))  // pairhmm_internal.cpp:578: queue for fp64
-            rescue_list[atomicAdd(rescue_count, 1u)] = pair;
-    }
+#define PHMM_SWEEP_RESCUE_LIST rescue_list
+#define PHMM_SWEEP_RESCUE_COUNT rescue_count
+#include "pairhmm_systolic_sweep.inc"
+#undef PHMM_SWEEP_RESCUE_LIST
+#undef PHMM_SWEEP_RESCUE_COUNT
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -361,203 +179,11 @@ __device__ __forceinline__ void systolic_ugo_sweep(const KernelArgs &a, uint32_t
     const uint32_t gidx = wg * (BT / G) + grp_in_block;  // BT: threads of the workgroup this sweep runs in
     const bool valid = gidx < count;
     const uint32_t pair = a.order[valid ? pos_first + gidx : 0];
-    const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
-    const uint32_t R = a.read_len[r], H = a.hap_len[h];
-    const uint32_t roff = a.read_off[r];
-    const uint32_t W = planes_words(H);
-    const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
-    const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
-
-    // ---- stage this pair's haplotype planes into LDS (kPlanes * W words, 16 lanes copy) ----
-    uint32_t *pl = lds + grp_in_block * a.lds_words_per_group;
-    {
-        const uint32_t *src = a.planes + a.plane_off[h];
-        for (uint32_t i = lane; i < kPlanes * W; i += G) pl[i] = src[i];
-    }
-
-    // ---- constants.  One gap-open and one gap-continuation quality for the whole batch (the host checked): the transition
-    // probabilities are four wave-uniform scalars; per row only what depends on the base quality and on padding remains ----
-    T p_yy[K], lo[K], hi[K];
-    T M[K], X[K], Y[K];
-    T PM[K > 1 ? K - 1 : 1];  // M[k] * p_mx of the anti-diagonal before: computed once in pass 2 (for X of the row below), used again
-                              // in the next step's pass 1 (for Y of the same row) -- the two products are the same number here
-    uint32_t cls_lo = 0, cls_hi = 0;  // 3-bit plane class per row, packed (K <= 16 -> 48 bits)
-    const T init_y = Num<T>::init_const() / static_cast<T>(H);  // rovaca/avx_512_float.cc:32
-    const int pad = G * K - static_cast<int>(R);                  // rows [0, pad) are boundary replicas
-    // kept per lane on purpose: with the four shared factors in SGPRs the sweep ran 6 % slower (a VALU instruction with an SGPR
-    // source issues more slowly on this chip than one whose sources are all VGPRs; measured on config 2, 8.25 ms against 7.76 ms)
-    const uint32_t g0 = a.read_ins[roff] & 127u, c0 = a.read_gcp[roff] & 127u;
-    const T p_mm = mmtab[((g0 * (g0 + 1)) >> 1) + g0];  // core/context.h:162-173 with ins == del
-    const T p_mx = ph2pr[g0];                            // == p_my
-    const T p_gapm = static_cast<T>(1.0) - ph2pr[c0];
-    const T p_xx = ph2pr[c0];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int row = static_cast<int>(lane) * K + k - pad;
-        uint32_t cls = 5;
-        if (row >= 0) {
-            const uint32_t at = roff + static_cast<uint32_t>(row);
-            const uint32_t _q = a.read_qual[at] & 127u;
-            p_yy[k] = p_xx;
-            const T dist = ph2pr[_q];
-            hi[k] = static_cast<T>(1.0) - dist;
-            lo[k] = Num<T>::div3(dist);
-            cls = read_class(a.read_bases[at]);
-            M[k] = 0;
-            X[k] = 0;
-            Y[k] = 0;
-        }
-        else {
-            // boundary replica: prior 0 kills M whatever p_mm is, X stays 0 because everything above it is 0, p_yy = 1 holds Y
-            p_yy[k] = 1;
-            hi[k] = 0;
-            lo[k] = 0;
-            M[k] = 0;
-            X[k] = 0;
-            Y[k] = init_y;
-        }
-        if (k < 10)
-            cls_lo |= cls << (3 * k);
-        else
-            cls_hi |= cls << (3 * (k - 10));
-    }
-#pragma unroll
-    for (int k = 0; k + 1 < K; ++k) PM[k] = 0;
-    __syncthreads();  // planes visible (each group only reads its own, but keep the block-wide fence simple)
-
-    // ---- the sweep ----
-    const uint32_t Tg = valid ? H + (G - 1) : 0;  // last step of this group
-    uint32_t Tmax = Tg;                           // wave-uniform loop bound
-    if (G <= 16) Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
-    if (G <= 32) Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
-    Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
-
-    uint32_t Tmin = Tg;  // until here every lane of the wave is busy once the pipeline is full
-    if (G <= 16) Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
-    if (G <= 32) Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
-    Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
-
-    uint32_t mask[K];
-    // The row above slot 0 travels between lanes in two register sets that swap roles every step: one holds that
-    // row at the current column (written by the DPP shift of this step), the other at the previous column (written
-    // one step earlier).  Lane 0 never receives anything, so its copies keep the boundary row (0, 0, init) for ever;
-    // the DPP's `old` operand is the destination itself, which costs no instruction.  Before a lane's first step
-    // both sets hold column 0 of the row above: Y[0][0] = init when that row is the boundary row or a replica of it
-    // (lane * K <= pad), and 0 when it is a read row (M[i][0] = X[i][0] = Y[i][0] = 0).
-    const T y_col0 = (static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
-    T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
-    T sumM = 0, sumX = 0;
-    const uint32_t wmax = W - 2;
-
-    auto reload = [&](uint32_t t) {
-        // every row's 32-column window of its match plane, starting at this lane's next column
-        const uint32_t jn = t > lane ? t - lane : 1u;  // 1-based
-        uint32_t w = (jn - 1) >> 5;
-        const uint32_t s = (jn - 1) & 31u;
-        w = w < wmax ? w : wmax;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t cls = k < 10 ? (cls_lo >> (3 * k)) & 7u : (cls_hi >> (3 * (k - 10))) & 7u;
-            const uint32_t *p = pl + cls * W + w;
-            const uint32_t w0 = p[0], w1 = p[1];
-            mask[k] = (w0 << s) | ((w1 >> 1) >> (31u - s));  // bits [s, s+32) of w0:w1, MSB first (s = 0..31)
-        }
-    };
-
-    // one anti-diagonal.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it at this column.
-    auto step = [&](T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
-        uM0 = dpp_shr1<G>(uM0, M[K - 1]);
-        uX0 = dpp_shr1<G>(uX0, X[K - 1]);
-        uY0 = dpp_shr1<G>(uY0, Y[K - 1]);
-        // Pass 1, bottom row first (in place, as in the general kernel); the M * p_my term of Y comes from the product pass 2 made
-        // of the same M one step ago -- except for the last row, whose M goes to the next lane
-#pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
-            uint32_t nm;
-            const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
-            mask[k] = nm;
-            const T prior = hit ? hi[k] : lo[k];
-            Y[k] = Num<T>::fma_(Y[k], p_yy[k], k == K - 1 ? M[K - 1] * p_mx : PM[k < K - 1 ? k : 0]);
-            const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
-            T tt = gM * p_mm;
-            tt = Num<T>::fma_(gX, p_gapm, tt);
-            tt = Num<T>::fma_(gY, p_gapm, tt);
-            M[k] = tt * prior;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // Pass 2, top row first: the insertion state chains down the column through the NEW M and X
-        T uM = uM0, uX = uX0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const T prod = uM * p_mx;  // k >= 1: the product of the new M[k - 1], kept for Y[k - 1] of the next step
-            X[k] = Num<T>::fma_(uX, p_xx, prod);
-            if (k >= 1) PM[k - 1] = prod;
-            uM = M[k];
-            uX = X[k];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
-        sumX = sumX + X[K - 1];
-    };
-    auto step_t = [&](uint32_t t) {
-        if (t & 1u)
-            step(aM, aX, aY, bM, bX, bY);
-        else
-            step(bM, bX, bY, aM, aX, aY);
-    };
-
-#ifndef PHMM_EXPERIMENT_REPEAT
-#define PHMM_EXPERIMENT_REPEAT 1  // tuning experiment (tools/build_variant.sh): sweep every loaded pair this many times -- what a
-#endif                            // read-stationary chain of haplotypes would save on per-pair set-up, measured without building it
-#pragma unroll 1
-    for (int rep = 0; rep < PHMM_EXPERIMENT_REPEAT; ++rep) {
-    if (PHMM_EXPERIMENT_REPEAT > 1) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const bool padrow = static_cast<int>(lane) * K + k < pad;
-            M[k] = 0;
-            X[k] = 0;
-            Y[k] = padrow ? init_y : static_cast<T>(0);
-        }
-#pragma unroll
-        for (int k = 0; k + 1 < K; ++k) PM[k] = 0;
-        aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
-        sumM = 0, sumX = 0;
-    }
-    uint32_t t = 1;
-    // fill: lane l starts at step l + 1
-    const uint32_t Tfill = Tmax < (uint32_t)(G - 1) ? Tmax : (uint32_t)(G - 1);
-    for (; t <= Tfill; ++t) {
-        if ((t & 31u) == 1u) reload(t);
-        if ((t > lane) && (t <= Tg)) step_t(t);
-    }
-    // steady state: every lane of all four pairs has work, no per-lane predicate
-    if (t <= Tmin && !(t & 1u)) {
-        step(bM, bX, bY, aM, aX, aY);
-        ++t;
-    }
-    for (; t + 1 <= Tmin; t += 2) {  // t is odd here: the two register sets swap roles without a single move
-        if ((t & 31u) == 1u) reload(t);
-        step(aM, aX, aY, bM, bX, bY);
-        step(bM, bX, bY, aM, aX, aY);
-    }
-    if (t <= Tmin) {
-        if ((t & 31u) == 1u) reload(t);
-        step(aM, aX, aY, bM, bX, bY);
-        ++t;
-    }
-    // drain: pairs with a shorter haplotype than the longest of the wave drop out group by group
-    for (; t <= Tmax; ++t) {
-        if ((t & 31u) == 1u) reload(t);
-        if (t <= Tg) step_t(t);
-    }
-    }
-    if (valid && lane == G - 1) {
-        const T res = sumM + sumX;
-        reinterpret_cast<T *>(a.out_raw)[pair] = res;
-        if (sizeof(T) == 4 && rescue_list && res < static_cast<T>(1e-28f))  // pairhmm_internal.cpp:578: queue for fp64
-            rescue_list[atomicAdd(rescue_count, 1u)] = pair;
-    }
+#define PHMM_SWEEP_RESCUE_LIST rescue_list
+#define PHMM_SWEEP_RESCUE_COUNT rescue_count
+#include "pairhmm_systolic_ugo_sweep.inc"
+#undef PHMM_SWEEP_RESCUE_LIST
+#undef PHMM_SWEEP_RESCUE_COUNT
 }
 
 }  // namespace phmm
