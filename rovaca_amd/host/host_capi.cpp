@@ -59,6 +59,10 @@ uint32_t rovaca_amd_poorly_modelled_reads(const double *lik, const int32_t *read
 int rovaca_amd_init_pairhmm_ptr_gpu(int device_id) { return rovaca::init_pairhmm_ptr_gpu(device_id) ? 1 : 0; }
 
 void rovaca_amd_batching_stats(uint64_t *regions, uint64_t *submissions) { rovaca::gpu_pairhmm_batching_stats(regions, submissions); }
+int rovaca_amd_batcher_stats(int batcher, int *device, uint64_t *regions, uint64_t *submissions)
+{
+    return rovaca::gpu_pairhmm_batcher_stats(batcher, device, regions, submissions);
+}
 
 // One region through rovaca::call_pairhmm (must have been installed).  Inputs are raw BAM-style reads (bases, quals,
 // mapping quality) and haplotype strings; out_hap_read is [n_haps][n_reads] (tail NaN), survivors[k] the original index

@@ -255,6 +255,7 @@ public:
         free_.push_back(&s);
     }
     std::atomic<uint64_t> regions{0}, submissions{0};
+    int device() const { return device_; }
 
 private:
     [[noreturn]] static void die(const char *what)
@@ -360,13 +361,23 @@ bool init_pairhmm_ptr_gpu(int device_id)
             g_batchers.push_back(new RegionBatcher(device_id, per_device));
         }
         else {
-            for (int d = 0; d < n; ++d) g_batchers.push_back(new RegionBatcher(d, per_device));
+            for (int d : rovaca_amd::batcher_devices("ROVACA_AMD_PAIRHMM_DEVICES", n)) g_batchers.push_back(new RegionBatcher(d, per_device));
         }
     }
     g_batching.store(batching);
     call_pairhmm = call_gpu_pairhmm;
     g_active.store(true);
     return true;
+}
+
+int gpu_pairhmm_batcher_stats(int batcher, int *device, uint64_t *regions, uint64_t *submissions)
+{
+    if (batcher >= 0 && (size_t)batcher < g_batchers.size()) {
+        if (device) *device = g_batchers[batcher]->device();
+        if (regions) *regions = g_batchers[batcher]->regions.load();
+        if (submissions) *submissions = g_batchers[batcher]->submissions.load();
+    }
+    return (int)g_batchers.size();
 }
 
 void gpu_pairhmm_batching_stats(uint64_t *regions, uint64_t *submissions)

@@ -67,6 +67,8 @@ bool init_pairhmm_ptr_gpu(int device_id = -1);
 // Regions evaluated and device submissions made by the cross-region batcher: workers that call
 // call_pairhmm concurrently are coalesced into one device batch per round trip.  ROVACA_AMD_PAIRHMM_BATCHING=0 disables it.
 void gpu_pairhmm_batching_stats(uint64_t *regions, uint64_t *submissions);
+// the same per batcher (one per device in use); returns the number of batchers whatever `batcher` is
+int gpu_pairhmm_batcher_stats(int batcher, int *device, uint64_t *regions, uint64_t *submissions);
 
 // Where the adapter's host time went so far: seconds per phase summed over all worker and dispatcher threads (names[i] describes
 // seconds[i]); returns the number of phases.  tools/adapter_bench.cpp prints it; profiles/ keeps a run.

@@ -4,6 +4,7 @@
 #define ROVACA_AMD_PAIRHMM_HOST_LOGIC_H_
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace rovaca_amd
@@ -40,6 +41,29 @@ std::vector<size_t> poorly_modelled_reads(const double *lik, const int32_t *read
 constexpr int32_t kMissingAlleleIndex = -1;
 void marginal_likelihoods_direct(const double *old, size_t n_old, size_t stride, size_t evidence_count, const int32_t *old2new,
                                  size_t n_new, double *out);
+
+// Which devices the adapters put a batcher on when the caller asks for all of them (init_pairhmm_ptr_gpu(-1), the Smith-Waterman
+// seam's default): every visible device once.  Test hook: `env_name` = "0,0,0" lists device ids explicitly, the same one several
+// times if need be -- N batchers on ONE card, so that the N-device path (round-robin over batchers, one stage pool and dispatcher set
+// each) runs on a one-GPU box.  Honoured only with PHMM_ENABLE_TEST_HOOKS=1 AND PHMM_MULTI_ALLOW_SHARED_DEVICE=1 (the same pair that
+// lets phmm_create_multi take a device twice); ids outside the visible devices are dropped.
+inline std::vector<int> batcher_devices(const char *env_name, int n_visible)
+{
+    std::vector<int> out;
+    const char *master = getenv("PHMM_ENABLE_TEST_HOOKS"), *shared = getenv("PHMM_MULTI_ALLOW_SHARED_DEVICE"), *list = getenv(env_name);
+    if (list && shared && master && master[0] && !(master[0] == '0' && master[1] == 0)) {
+        for (const char *q = list; *q;) {
+            char *end = nullptr;
+            const long d = strtol(q, &end, 10);
+            if (end == q) break;
+            if (d >= 0 && d < n_visible) out.push_back((int)d);
+            q = *end ? end + 1 : end;
+        }
+    }
+    if (out.empty())
+        for (int d = 0; d < n_visible; ++d) out.push_back(d);
+    return out;
+}
 
 }  // namespace rovaca_amd
 #endif

@@ -1,5 +1,6 @@
 // sw_gpu_engine.cpp -- see sw_gpu_engine.h.  Host glue only: the alignment itself is include/smithwaterman_hip.h.
 #include "sw_gpu_engine.h"
+#include "pairhmm_host_logic.h"
 
 #include <atomic>
 #include <condition_variable>
@@ -326,8 +327,12 @@ void start_batchers()
     n = n < 1 ? 1 : n > 16 ? 16 : n;
     // with round-robin devices every device gets its queue and dispatchers (a dispatcher's context is created on its own thread)
     const int fixed = g_sw_device.load();
-    const int devices = fixed < 0 ? std::max(1, swhip_device_count()) : 1;
-    for (int d = 0; d < devices; ++d) g_sw_batchers.push_back(new SwBatcher(fixed < 0 ? d : fixed, n));
+    if (fixed >= 0) {
+        g_sw_batchers.push_back(new SwBatcher(fixed, n));
+        return;
+    }
+    // (test hook ROVACA_AMD_SW_DEVICES=0,0: several queues on one card -- pairhmm_host_logic.h, batcher_devices)
+    for (int d : rovaca_amd::batcher_devices("ROVACA_AMD_SW_DEVICES", std::max(1, swhip_device_count()))) g_sw_batchers.push_back(new SwBatcher(d, n));
 }
 
 // a request as the worker prepares it: result slots sized, CIGAR buffer with room for the usual handful of elements per alignment
@@ -425,6 +430,8 @@ bool sw_hip_align_batch_finish(SwTicket &&ticket, std::vector<SwAlignment> &out)
     out = std::move(st.out);
     return st.ok;
 }
+
+int sw_hip_batcher_count() { return (int)g_sw_batchers.size(); }
 
 void sw_hip_batching_stats(uint64_t *requests, uint64_t *submissions)
 {

@@ -98,6 +98,7 @@ SwTicket sw_hip_align_batch_begin(const SwJob *jobs, size_t n, const sw_paramete
 bool sw_hip_align_batch_finish(SwTicket &&ticket, std::vector<SwAlignment> &out);
 // requests served and device calls made by the dispatchers
 void sw_hip_batching_stats(uint64_t *requests, uint64_t *submissions);
+int sw_hip_batcher_count();  // queues in use (one per device; 0 before the first batched call)
 
 }  // namespace rovaca
 #endif

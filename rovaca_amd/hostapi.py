@@ -49,6 +49,8 @@ def lib():
     L.rovaca_amd_call_region.restype = C.c_int32
     L.rovaca_amd_batching_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rovaca_amd_batching_stats.restype = None
+    L.rovaca_amd_batcher_stats.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rovaca_amd_batcher_stats.restype = C.c_int
     _LIB = L
     return L
 
@@ -58,6 +60,18 @@ def batching_stats():
     r, s = C.c_uint64(), C.c_uint64()
     lib().rovaca_amd_batching_stats(C.byref(r), C.byref(s))
     return int(r.value), int(s.value)
+
+
+def batcher_stats():
+    """[(device, regions, submissions)] per batcher of the adapter (one batcher per device in use)."""
+    out, n, i = [], 1, 0
+    while i < n:
+        d, r, s = C.c_int(-1), C.c_uint64(0), C.c_uint64(0)
+        n = lib().rovaca_amd_batcher_stats(i, C.byref(d), C.byref(r), C.byref(s))
+        if i < n:
+            out.append((d.value, r.value, s.value))
+        i += 1
+    return out
 
 
 def init_pairhmm_ptr_gpu(device=-1):

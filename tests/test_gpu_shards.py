@@ -153,9 +153,20 @@ def test_bench_refuses_more_gpus_than_there_are():
                         "--scale", "0.01", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_dev + 1), "--oversubscribe", "--steps", "2",
-                        "--warmup", "1", "--scale", "0.02", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--scale", "0.02", "--cpu-threads", "4"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1  # one line, nothing else on stdout
     line = json.loads(r.stdout.strip().splitlines()[-1])
+    # the N-slice line carries what the one-GPU line carries: the CPU leg with its bit check, the PCIe-inclusive one-shot call through
+    # phmm_multi_compute, and the drop-in adapter over N batchers (one per slice's device, dealt round-robin)
+    assert line["cpu_baseline"]["bit_identical_to_gpu_fp32"] is True and line["max_abs_delta_log10_vs_cpu"] == 0.0
+    assert line["e2e"]["identical_to_resident_path"] is True and line["value_e2e_pcie_inclusive"] > 0
+    ad = line["adapter"]
+    assert "error" not in ad, ad
+    assert ad["bit_identical_to_resident_path"] is True and ad["value"] > 0 and ad["synchronous_seam"]["value"] > 0
+    assert len(ad["batchers"]) == n_dev + 1 and all(b["regions"] > 0 and b["submissions"] > 0 for b in ad["batchers"])
+    per = [b["regions"] for b in ad["batchers"]]
+    assert max(per) - min(per) <= max(4, sum(per) // 100)
     # the rehearsal runs n_dev + 1 SLICES (the whole N-slice path) on the devices there are and says so: n_gpus stays physical
     assert line["n_gpus"] == n_dev and line["metric"] == "PairHMM GCUPS" and line["value"] > 0
     assert line["config"]["slices"] == n_dev + 1 and len(line["per_device_ms_per_step"]) == n_dev + 1 and "note" in line
