@@ -119,13 +119,59 @@ static int stages_at_start()
     return std::max(2, std::min(kStagesMax, e ? atoi(e) : 32));
 }
 
+// The fill cursors of a stage as ONE 128-bit word, reserved with a compare-and-swap: regions | reads | haplotypes | generation |
+// closed in the low half, bytes | pairs in the high half.  Until round 3 they were five integers behind the batcher's mutex, and
+// with 64-128 workers on a 16-core share a worker preempted inside that critical section held everybody up: `reserve` cost 11.7 /
+// 33 us per region, more than filling the stage, the log10 and H8 together (profiles/r3_adapter_host_profile.txt).  Now a
+// reservation is lock-free; the mutex is taken to roll a full stage over, by a dispatcher, and by the last reader that recycles one.
+struct alignas(16) Cursor
+{
+    uint64_t lo = kClosed, hi = 0;  // (a stage that is not the open one is closed: a stale reservation cannot land in it)
+    static constexpr uint64_t kClosed = 1;
+    bool closed() const { return (lo & kClosed) != 0; }
+    uint32_t generation() const { return (uint32_t)(lo >> 1) & 0x7FFFu; }
+    uint32_t regions() const { return (uint32_t)(lo >> 48); }
+    uint32_t reads() const { return (uint32_t)(lo >> 32) & 0xFFFFu; }
+    uint32_t haps() const { return (uint32_t)(lo >> 16) & 0xFFFFu; }
+    uint32_t bytes() const { return (uint32_t)(hi >> 32); }
+    uint32_t pairs() const { return (uint32_t)hi; }
+    static Cursor make(uint32_t regions, uint32_t reads, uint32_t haps, uint32_t bytes, uint32_t pairs, uint32_t gen, bool closed)
+    {
+        Cursor c;
+        c.lo = ((uint64_t)regions << 48) | ((uint64_t)reads << 32) | ((uint64_t)haps << 16) | ((uint64_t)(gen & 0x7FFFu) << 1) | (closed ? kClosed : 0);
+        c.hi = ((uint64_t)bytes << 32) | pairs;
+        return c;
+    }
+};
+// lock cmpxchg16b (every x86-64 this code can meet has it; the attribute spares the including build a -mcx16)
+__attribute__((target("cx16"))) static inline bool cursor_cas(Cursor *p, Cursor &expected, const Cursor &desired)
+{
+    const unsigned __int128 e = ((unsigned __int128)expected.hi << 64) | expected.lo, d = ((unsigned __int128)desired.hi << 64) | desired.lo;
+    const unsigned __int128 seen = __sync_val_compare_and_swap(reinterpret_cast<unsigned __int128 *>(p), e, d);
+    if (seen == e) return true;
+    expected.lo = (uint64_t)seen;
+    expected.hi = (uint64_t)(seen >> 64);
+    return false;
+}
+static inline Cursor cursor_peek(const Cursor *p)  // two relaxed loads: may be torn, which the compare-and-swap that follows catches
+{
+    Cursor c;
+    c.lo = __atomic_load_n(&p->lo, __ATOMIC_ACQUIRE);
+    c.hi = __atomic_load_n(&p->hi, __ATOMIC_ACQUIRE);
+    return c;
+}
+
 struct StageSlot
 {
     phmm_stage *st = nullptr;
     phmm_stage_view v{};
-    // fill cursors: written under the batcher's mutex while this is the open stage, frozen once a dispatcher has taken it
-    uint32_t n_regions = 0, n_reads = 0, n_haps = 0, bytes = 0, n_pairs = 0;
-    int32_t min_q = 0, pcr_model = 0;
+    Cursor cur;  // the fill cursors while this is the open stage
+    // ... and as frozen by whoever closed it (a dispatcher, or the worker that found it full)
+    uint32_t n_regions = 0, n_reads = 0, n_haps = 0;
+    // written under the batcher's mutex before the stage is published as the open one (the release store of its cursor word); a worker
+    // reads them after it has seen that word open -- possibly through a stale pointer to a stage that has been recycled and opened
+    // again meanwhile, which is then simply the open stage
+    std::atomic<int32_t> min_q{0}, pcr_model{0};
     std::atomic<uint32_t> committed{0};  // regions whose bytes are in place
     std::atomic<uint32_t> state{0};      // futex word: 0 filling / on the device, 1 results in the stage, 2 failed
     std::atomic<uint32_t> waiters{0};    // workers asleep on `state`
@@ -187,51 +233,75 @@ public:
         const uint64_t n_pairs = (uint64_t)n_reads * n_haps;
         if (n_reads > kStageCaps.max_reads || n_haps > kStageCaps.max_haps || bytes > kStageCaps.max_bytes || n_pairs > kStageCaps.max_pairs)
             return false;
-        bool wake = false;
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            for (;;) {
-                if (!open_) {
-                    if (free_.empty()) {
-                        if (n_slots_ >= kStagesMax) return false;
-                        ++n_slots_;  // counted before the lock is dropped: the pool never overshoots
-                        lk.unlock();
-                        StageSlot *fresh = new_slot(false);
-                        lk.lock();
-                        free_.push_back(fresh);
-                        continue;
-                    }
-                    open_ = free_.back();
-                    free_.pop_back();
-                    open_->min_q = min_q;
-                    open_->pcr_model = pcr_model;
-                }
-                StageSlot &s = *open_;
-                const bool fits = s.n_regions < kStageCaps.max_regions && s.n_reads + n_reads <= kStageCaps.max_reads &&
-                                  s.n_haps + n_haps <= kStageCaps.max_haps && s.bytes + bytes <= kStageCaps.max_bytes &&
-                                  s.n_pairs + n_pairs <= kStageCaps.max_pairs;
+        for (;;) {
+            StageSlot *s = open_.load(std::memory_order_acquire);
+            if (s) {
+                Cursor c = cursor_peek(&s->cur);
                 // one device batch per distinct (threshold, PCR model); in practice they are process-wide constants
-                if (fits && s.min_q == min_q && s.pcr_model == pcr_model) break;
-                closed_.push_back(open_);  // full: a dispatcher takes it as it is
-                open_ = nullptr;
-                wake = true;
+                while (!c.closed() && s->min_q.load(std::memory_order_relaxed) == min_q && s->pcr_model.load(std::memory_order_relaxed) == pcr_model && c.regions() < kStageCaps.max_regions &&
+                       c.reads() + n_reads <= kStageCaps.max_reads && c.haps() + n_haps <= kStageCaps.max_haps &&
+                       (uint64_t)c.bytes() + bytes <= kStageCaps.max_bytes && c.pairs() + n_pairs <= kStageCaps.max_pairs) {
+                    const Cursor n = Cursor::make(c.regions() + 1, c.reads() + n_reads, c.haps() + n_haps, c.bytes() + bytes,
+                                                  c.pairs() + (uint32_t)n_pairs, c.generation(), false);
+                    if (!cursor_cas(&s->cur, c, n)) continue;  // somebody else moved the cursors (c has what is there now): look again
+                    rv.slot = s;
+                    rv.region = c.regions();
+                    rv.read_first = c.reads();
+                    rv.hap_first = c.haps();
+                    rv.byte_first = c.bytes();
+                    s->readers.fetch_add(1, std::memory_order_relaxed);  // (before this region's commit, which every reader's release follows)
+                    s->v.regions[rv.region] = phmm_region{rv.read_first, n_reads, rv.hap_first, n_haps};
+                    if (idle_.load(std::memory_order_acquire) != 0) {
+                        // a dispatcher is asleep (or about to be): it wakes up while this worker is still writing its bytes.  Passing
+                        // through the mutex orders this reservation before the dispatcher's predicate check or after its wait.
+                        { std::lock_guard<std::mutex> lk(mu_); }
+                        cv_.notify_one();
+                    }
+                    return true;
+                }
             }
-            StageSlot &s = *open_;
-            rv.slot = &s;
-            rv.region = s.n_regions++;
-            rv.read_first = s.n_reads;
-            rv.hap_first = s.n_haps;
-            rv.byte_first = s.bytes;
-            s.n_reads += n_reads;
-            s.n_haps += n_haps;
-            s.bytes += bytes;
-            s.n_pairs += (uint32_t)n_pairs;
-            s.readers.fetch_add(1, std::memory_order_relaxed);
-            s.v.regions[rv.region] = phmm_region{rv.read_first, n_reads, rv.hap_first, n_haps};
-            wake = wake || idle_ != 0;
+            // the open stage is full, closed, of another (threshold, model), or there is none: roll over, under the mutex
+            bool wake = false;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (open_.load(std::memory_order_relaxed) != s) continue;  // somebody rolled over meanwhile
+                if (s) {
+                    if (freeze(*s) != 0) {
+                        closed_.push_back(s);  // full: a dispatcher takes it as it is
+                        wake = true;
+                    }
+                    else {
+                        free_.push_back(s);  // (nothing in it: a stage opened for another (threshold, model))
+                    }
+                    open_.store(nullptr, std::memory_order_relaxed);
+                }
+                if (free_.empty()) {
+                    if (n_slots_ >= kStagesMax) {
+                        lk.unlock();
+                        if (wake) cv_.notify_one();
+                        return false;
+                    }
+                    ++n_slots_;  // counted before the lock is dropped: the pool never overshoots
+                    lk.unlock();
+                    if (wake) cv_.notify_one();
+                    StageSlot *fresh = new_slot(false);
+                    lk.lock();
+                    free_.push_back(fresh);
+                    wake = false;
+                    if (open_.load(std::memory_order_relaxed) != nullptr) continue;  // somebody opened one while this one was being made
+                }
+                StageSlot *n = free_.back();
+                free_.pop_back();
+                n->min_q.store(min_q, std::memory_order_relaxed);
+                n->pcr_model.store(pcr_model, std::memory_order_relaxed);
+                n->n_regions = n->n_reads = n->n_haps = 0;
+                const Cursor fresh_cur = Cursor::make(0, 0, 0, 0, 0, n->cur.generation() + 1, false);
+                __atomic_store_n(&n->cur.hi, fresh_cur.hi, __ATOMIC_RELAXED);
+                __atomic_store_n(&n->cur.lo, fresh_cur.lo, __ATOMIC_RELEASE);  // (no reservation can be in flight on a closed stage)
+                open_.store(n, std::memory_order_release);
+            }
+            if (wake) cv_.notify_one();
         }
-        if (wake) cv_.notify_one();  // the dispatcher wakes up while this worker is still writing its bytes
-        return true;
     }
     static void commit(const Reservation &rv) { rv.slot->committed.fetch_add(1, std::memory_order_release); }
     // blocks until the stage's results are in; returns the submission's status
@@ -248,7 +318,7 @@ public:
     void release(StageSlot &s)
     {
         if (s.readers.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
-        s.n_regions = s.n_reads = s.n_haps = s.bytes = s.n_pairs = 0;
+        s.n_regions = s.n_reads = s.n_haps = 0;  // (the cursor word stays closed until the stage is opened again)
         s.committed.store(0, std::memory_order_relaxed);
         s.state.store(0, std::memory_order_release);
         std::lock_guard<std::mutex> lk(mu_);
@@ -263,6 +333,26 @@ private:
         // the reference's convention for an unrecoverable engine failure: log, exit (pairhmm_engine.cpp:32-35)
         fprintf(stderr, "[rovaca_amd] pairhmm: %s: %s\n", what, phmm_last_error());
         exit(EXIT_FAILURE);
+    }
+    // closes a stage for reservations and freezes its cursors into the plain fields; returns the regions in it
+    static uint32_t freeze(StageSlot &s)
+    {
+        Cursor c = cursor_peek(&s.cur);
+        for (;;) {
+            if (c.closed()) break;
+            Cursor n = c;
+            n.lo |= Cursor::kClosed;
+            if (cursor_cas(&s.cur, c, n)) break;
+        }
+        s.n_regions = c.regions();
+        s.n_reads = c.reads();
+        s.n_haps = c.haps();
+        return s.n_regions;
+    }
+    bool open_has_regions() const
+    {
+        const StageSlot *o = open_.load(std::memory_order_acquire);
+        return o && cursor_peek(&o->cur).regions() != 0;
     }
     StageSlot *new_slot(bool count = true)
     {
@@ -283,18 +373,19 @@ private:
             StageSlot *s = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                ++idle_;
-                cv_.wait(lk, [&] { return !closed_.empty() || (open_ && open_->n_regions != 0); });
-                --idle_;
+                idle_.fetch_add(1, std::memory_order_acq_rel);
+                cv_.wait(lk, [&] { return !closed_.empty() || open_has_regions(); });
+                idle_.fetch_sub(1, std::memory_order_acq_rel);
                 if (!closed_.empty()) {
                     s = closed_.front();
                     closed_.pop_front();
                 }
                 else {
-                    s = open_;
-                    open_ = nullptr;  // the next worker opens a fresh stage
+                    s = open_.load(std::memory_order_relaxed);
+                    freeze(*s);                                     // no reservation lands in it from here on
+                    open_.store(nullptr, std::memory_order_release);  // the next worker opens a fresh stage
                 }
-                if (idle_ != 0 && (!closed_.empty() || (open_ && open_->n_regions != 0))) cv_.notify_one();
+                if (idle_.load(std::memory_order_relaxed) != 0 && (!closed_.empty() || open_has_regions())) cv_.notify_one();
             }
             clk.lap(kProfDispIdle);
             // the regions counted in are being written right now: a few microseconds each
@@ -305,7 +396,8 @@ private:
                     std::this_thread::yield();  // (a writer that lost its core: let it run)
             }
             clk.lap(kProfDispCommitSpin);
-            const phmm_stage_params prm{s->min_q, s->pcr_model, rovaca_amd::kDefaultGapOpen, rovaca_amd::kDefaultGapCont};
+            const phmm_stage_params prm{s->min_q.load(std::memory_order_relaxed), s->pcr_model.load(std::memory_order_relaxed), rovaca_amd::kDefaultGapOpen,
+                                        rovaca_amd::kDefaultGapCont};
             int rc = phmm_stage_submit(ctx, s->st, s->n_regions, s->n_reads, s->n_haps, &prm);
             clk.lap(kProfDispSubmit);
             if (rc == PHMM_OK) rc = phmm_stage_wait(ctx, s->st, nullptr);
@@ -324,10 +416,11 @@ private:
     phmm_context *owner_ = nullptr;  // the context the stages are created on (their device buffers belong to its device)
     std::mutex mu_;
     std::condition_variable cv_;
-    StageSlot *open_ = nullptr;       // the stage that is filling
-    std::deque<StageSlot *> closed_;  // full stages waiting for a dispatcher
-    std::vector<StageSlot *> free_;
-    int n_slots_ = 0, idle_ = 0;      // guarded by mu_
+    std::atomic<StageSlot *> open_{nullptr};  // the stage that is filling (its cursors: StageSlot::cur)
+    std::deque<StageSlot *> closed_;          // full stages waiting for a dispatcher (guarded by mu_)
+    std::vector<StageSlot *> free_;           // (guarded by mu_)
+    int n_slots_ = 0;                         // (guarded by mu_)
+    std::atomic<int> idle_{0};                // dispatchers asleep or about to be
     std::vector<std::thread> threads_;
 };
 

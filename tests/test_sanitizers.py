@@ -46,6 +46,12 @@ def test_batchers_are_race_free_under_tsan_and_clean_under_asan():
         r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
         assert r.returncode == 0, r.stdout + r.stderr
         assert "0 mismatches" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr
+        # ... and heavily oversubscribed: 48 workers on whatever cores there are -- the stage reservation is a lock-free compare-and-swap
+        # on a 128-bit cursor word (pairhmm_gpu_engine.cpp), and a worker preempted half way through one must hold nobody up
+        r = subprocess.run([exe], capture_output=True, text=True,
+                           env=dict(os.environ, BATCHER_THREADS="48", TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "0 mismatches" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr
         # the same harness (both seams, synchronous and in two halves, tickets dropped unfinished) under AddressSanitizer + UBSan:
         # lifetimes of the tickets' buffers against the dispatchers that write into them (leak check off: the dispatcher threads
         # and their queues are never torn down, by design)
