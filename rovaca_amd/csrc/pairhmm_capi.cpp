@@ -103,10 +103,7 @@ int phmm_create(int device_id, void *stream, phmm_context **out)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
-    for (int i = 0; i < phmm_context::kSideStreams && e == hipSuccess; ++i) {
-        e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
-    }
+    // (the side streams are made when a pass first fans out: ensure_side_streams)
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         impl::phmm_destroy(c);
@@ -193,6 +190,21 @@ void phmm_destroy(phmm_context *c)
     delete c->prep_pool;
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+// The side streams of a context (and their join events) exist from the first pass that needs them.  Most contexts never do: a
+// dispatcher of the drop-in adapter submits stages whose reads fall into one launch, and the runtime multiplexes a process's streams onto
+// GPU_MAX_HW_QUEUES hardware queues -- sixteen streams made at start-up by the adapter's four contexts, on top of the caller's own, meant
+// that two dispatchers' main streams could end up sharing a queue (whether they did depended on which thread created its streams first:
+// the synchronous seam measured 2 200 or 2 950 GCUPS from one run of bench.py to the next, round 4).
+int ensure_side_streams(phmm_context *c)
+{
+    if (c->cpu || c->side[0]) return PHMM_OK;
+    for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming));
+    }
+    return PHMM_OK;
 }
 
 int phmm_synchronize(phmm_context *c)
@@ -727,6 +739,8 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
     rb->last_fp32_launches = (uint32_t)launches.size();
     const bool fan_out = launches.size() > 1;
     if (fan_out) {
+        const int rc_side = ensure_side_streams(c);
+        if (rc_side != PHMM_OK) return rc_side;
         HIP_TRY(hipEventRecord(c->fork, c->stream));
         for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->fork, 0));
     }
@@ -832,7 +846,7 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
     // the stream set the launches go to: the context's own, or the one handed in (the chunk pipeline's collector thread re-runs a
     // chunk's underflowed pairs on a lane of its own while the calling thread keeps enqueuing sweeps on the context's)
     hipStream_t s_main = on ? on->stream : c->stream;
-    hipStream_t const *s_side = on ? on->side : c->side;
+    hipStream_t const *s_side = on ? on->side : c->side;  // (the context's own: made on the first fan-out, below)
     hipEvent_t s_fork = on ? on->fork : c->fork;
     hipEvent_t const *s_join = on ? on->join : c->join;
 
@@ -921,6 +935,12 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
     }
     HIP_TRY(rb->carry64.alloc(carry_total));
     const bool fan_out = launches.size() > 1;
+    if (fan_out && !on) {
+        const int rc_side = ensure_side_streams(c);
+        if (rc_side != PHMM_OK) return rc_side;
+        s_side = c->side;
+        s_join = c->join;
+    }
     if (fan_out) {
         HIP_TRY(hipEventRecord(s_fork, s_main));
         for (int i = 0; i < c->n_side; ++i) HIP_TRY(hipStreamWaitEvent(s_side[i], s_fork, 0));

@@ -143,6 +143,10 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
                            double *out_log10, phmm_stats *stats)
 {
     HIP_TRY(hipSetDevice(c->device));
+    {
+        const int rc_side = ensure_side_streams(c);  // the upload stream is one of them
+        if (rc_side != PHMM_OK) return rc_side;
+    }
     constexpr int S = phmm_context::kChunkSlots;
     for (int i = 0; i < S; ++i) {
         if (!c->chunk_slot[i]) {

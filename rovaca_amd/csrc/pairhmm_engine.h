@@ -348,6 +348,7 @@ using phmm_detail::guarded;
 namespace impl
 {
 // pairhmm_capi.cpp: one pass over a resident batch, enqueued on the context's stream set; the CPU backend's two steps
+int ensure_side_streams(phmm_context *c);  // the context's side streams and join events, made on first use
 int sweep_fp32(phmm_context *c, phmm_resident *rb);
 int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLane *on = nullptr);
 int cpu_upload(phmm_context *c, const phmm_batch *b, phmm_resident *rb);

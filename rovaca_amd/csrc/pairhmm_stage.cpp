@@ -368,7 +368,8 @@ int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint3
     rc = enqueue();
     if (rc != PHMM_OK) {
         (void)hipStreamSynchronize(c->stream);
-        for (int i = 0; i < c->n_side; ++i) (void)hipStreamSynchronize(c->side[i]);
+        for (int i = 0; i < c->n_side; ++i)
+            if (c->side[i]) (void)hipStreamSynchronize(c->side[i]);
         st->n_pairs = 0;
         st->n_regions = 0;
         return rc;
