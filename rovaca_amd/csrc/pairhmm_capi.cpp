@@ -1198,11 +1198,17 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
         const bool chunkable = n_all >= chunked_min_pairs();
         if (chunkable) {
             const unsigned all = std::max(1u, host_threads()) - 1u, want = n_all >= (1u << 19) ? all : std::min(3u, all);
-            if (c->pack_pool && c->pack_pool->helpers() < want) {  // a large batch after mid-size ones: the pool grows once
+            // a large batch after mid-size ones: the pool grows once.  The REQUEST is remembered, not the threads it yielded: in a process
+            // near its thread limit a pool comes up short for good, and comparing helpers() rebuilt it -- joining and respawning
+            // threads -- on every call
+            if (c->pack_pool && c->pack_pool_asked < want) {
                 delete c->pack_pool;
                 c->pack_pool = nullptr;
             }
-            if (!c->pack_pool) c->pack_pool = new phmm_detail::HostPool(want);
+            if (!c->pack_pool) {
+                c->pack_pool = new phmm_detail::HostPool(want);
+                c->pack_pool_asked = want;
+            }
         }
         if (chunkable && !c->fin_pool) c->fin_pool = new phmm_detail::HostPool(3);
         phmm_detail::PoolScope pool(chunkable ? c->pack_pool : nullptr);

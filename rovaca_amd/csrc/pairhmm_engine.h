@@ -143,6 +143,7 @@ struct phmm_context
         hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr}, done = nullptr;
     } lane2, rescue_lane;  // rescue_lane: where the chunk pipeline's collector re-runs a chunk's underflowed pairs
     phmm_detail::HostPool *pack_pool = nullptr, *fin_pool = nullptr;  // helper threads of the two sides of that pipeline
+    unsigned pack_pool_asked = 0;  // helpers pack_pool was made for (it may have fewer: thread creation can fail)
     phmm_detail::HostPool *prep_pool = nullptr;  // its prepare workers: chunks k + 1, k + 2, ... are packed and binned while chunk k is enqueued
     phmm_detail::BinScratch prep_scratch[8];     // one binning scratch per prepare worker
     phmm_detail::BinScratch bin_scratch;       // host scratch of the length binning, kept between calls

@@ -110,7 +110,17 @@ def test_stage_rejects_what_does_not_fit_or_overlaps(engine):
     raw, l10, _ = st.log10(0, b.n_pairs)
     want_raw, want_l10, _ = engine.compute(b, prep=(mapq, 18, 3))
     assert np.array_equal(raw.view(np.uint32), want_raw.view(np.uint32)) and np.array_equal(l10, want_l10)
-    st.close()
+    # ... and a submission that fails AFTER one that succeeded does not leave the earlier batch's numbers readable as its own
+    st.read_len[3] = 0
+    with pytest.raises(capi.PhmmError):
+        st.submit(*n)
+    st.wait()
+    with pytest.raises(capi.PhmmError, match="did not succeed"):
+        st.log10(0, b.n_pairs)
+    assert st.pair_first(1) == 0
+    st.fill(b, capi.regions_of(b), mapq)
+    st.submit(*n)
+    st.close()  # with the submission still in flight: destroy waits for it
 
 
 @pytest.mark.parametrize("model", [3, 1, 2, 0])

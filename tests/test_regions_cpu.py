@@ -137,5 +137,24 @@ def test_compute_regions_on_the_cpu_backend_against_the_oracle(model):
         stg.wait()
         r2, l2, resc = stg.log10(0, b.n_pairs)
         assert np.array_equal(r2.view(np.uint32), raw.view(np.uint32)) and np.array_equal(l2, l10) and resc == st.n_rescued
+    # a submission that FAILS (a read of length 0; more reads than the stage holds) must not leave the batch before it readable as its own:
+    # the stage is empty afterwards -- phmm_stage_log10 refuses, phmm_stage_pair_first answers 0 -- until a submission succeeds again
+    n = stg.fill(b, capi.regions_of(b), mapq)
+    stg.read_len[3] = 0
+    with pytest.raises(capi.PhmmError, match="length 0"):
+        stg.submit(*n, 18, model)
+    stg.wait()  # (nothing in flight: returns at once)
+    with pytest.raises(capi.PhmmError, match="did not succeed"):
+        stg.log10(0, b.n_pairs)
+    assert stg.pair_first(1) == 0
+    with pytest.raises(capi.PhmmError, match="capacity"):
+        stg.submit(n[0], 129, n[2], 18, model)
+    with pytest.raises(capi.PhmmError, match="did not succeed"):
+        stg.log10(0, 1)
+    n = stg.fill(b, capi.regions_of(b), mapq)
+    stg.submit(*n, 18, model)
+    stg.wait()
+    r2, l2, _ = stg.log10(0, b.n_pairs)
+    assert np.array_equal(r2.view(np.uint32), raw.view(np.uint32)) and np.array_equal(l2, l10)
     stg.close()
     eng.close()
