@@ -17,6 +17,7 @@
 #include <thread>
 
 #include <climits>
+#include <cpuid.h>
 #include <linux/futex.h>
 #include <pthread.h>
 #include <sys/syscall.h>
@@ -440,6 +441,14 @@ bool init_pairhmm_ptr_gpu(int device_id)
     // first HIP call -- this function is the reference's init_pairhmm_ptr, which runs first thing on the main thread -- and never
     // overrides a value the user has set.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    {
+        // the stage reservation is a cmpxchg16b (cursor_cas): CPUID.1:ECX bit 13; no second code path is built for a CPU without it
+        unsigned a = 0, b = 0, c = 0, d = 0;
+        if (!__get_cpuid(1, &a, &b, &c, &d) || !(c & (1u << 13))) {
+            fprintf(stderr, "rovaca_amd: this CPU has no cmpxchg16b; the GPU PairHMM adapter is not available\n");
+            return false;
+        }
+    }
     const int n = phmm_device_count();
     if (n <= 0 || device_id >= n) return false;
     g_device.store(device_id);
