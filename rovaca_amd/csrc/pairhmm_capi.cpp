@@ -676,6 +676,22 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         carry_total += (phmm::team_carry_values(pl.teams, pl.sh.waves, bin.max_hap_len + 1, pl.sh.lanes) + 63) & ~size_t(63);
     }
     HIP_TRY(rb->carry32.alloc(carry_total));
+    // The rescue queue of a striped range is a list in processing order with holes (KernelArgs::sparse_order) when the team / band
+    // kernels feed it (the one-pass kernels that take reads of 257-512 bases append): filled with "no pair" before the pass.
+    // PHMM_RESCUE_APPEND=1 (test hook): the appended list of rounds 1-3, whose order is the one the fp32 teams finish in.
+    const bool in_place = phmm_hook("PHMM_RESCUE_APPEND") == nullptr;
+    auto striped_kernel_bin = [&](const Bin &bin) {
+        return bin.rows_per_lane == 0 && !(bin.max_read_len <= 64u * phmm::kMaxRowsPerLaneWide && bin.max_hap_len <= kSinglePassMaxHap &&
+                                           !phmm_hook("PHMM_NO_WIDE_SINGLE_PASS"));
+    };
+    for (int qi = 0; qi < kQueues; ++qi) rb->queue_sparse[qi] = false;
+    for (const Bin &bin : rb->bins)
+        if (bin.queue >= 1 && bin.queue <= 4 && in_place && striped_kernel_bin(bin)) rb->queue_sparse[bin.queue] = true;
+    for (const Bin &bin : rb->bins)
+        if (bin.queue >= 1 && bin.queue <= 4 && !striped_kernel_bin(bin)) rb->queue_sparse[bin.queue] = false;  // (a queue is fed one way)
+    for (const Bin &bin : rb->bins)
+        if (rb->queue_sparse[bin.queue])
+            HIP_TRY(hipMemsetAsync(rb->rescue_list.p + bin.first, 0xFF, (size_t)bin.count * sizeof(uint32_t), c->stream));
     // The launches of the pass.  A striped bin is one launch.  Single-pass bins are one launch each too -- unless the batch takes ragged
     // launches (the Rovaca case; pairhmm_kernels_ragged.hip): then a run of single-pass bins is cut into the K ranges that share a
     // kernel and every range with more than one bin is ONE launch whose workgroups pick their class's K, longest rows first.
@@ -828,6 +844,7 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         }
         else {
             const StripedPlan &pl = plans[i];
+            a.sparse_order = rb->queue_sparse[bin.queue] ? 1u : 0u;
             HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, pl.sh.waves, pl.sh.lanes, a, rb->carry32.p + pl.carry_at,
                                              bin.max_hap_len + 1, pl.teams, stream));
         }
@@ -913,9 +930,9 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
         const QueuePlan &p = q[qi];
         if (p.cap == 0) continue;
         RescueLaunch *into = nullptr;
-        if (merge)
+        if (merge && !rb->queue_sparse[qi])  // (a list with holes is walked position by position: a launch of its own)
             for (RescueLaunch &L : launches)
-                if (L.rows == p.rows && L.sh.lanes == p.sh.lanes && L.sh.waves == p.sh.waves &&
+                if (!rb->queue_sparse[L.queues[0]] && L.rows == p.rows && L.sh.lanes == p.sh.lanes && L.sh.waves == p.sh.waves &&
                     L.queues.size() < (size_t)phmm::kMaxRescueQueuesPerLaunch)
                     into = &L;
         if (!into) {
@@ -967,6 +984,10 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
             const int qi = L.queues[0];
             a.order = rb->rescue_list.p + q[qi].base;
             a.n_pairs_dev = rb->rescue_count.p + qi;
+            if (rb->queue_sparse[qi]) {  // a striped range's queue: every position of the range, holes skipped (KernelArgs::sparse_order)
+                a.n_pairs = q[qi].cap;
+                a.sparse_order = 1;
+            }
         }
         else {
             a.order = rb->rescue_list.p;

@@ -34,11 +34,19 @@ bool plan_chunks(const phmm_batch *b, std::vector<ChunkWindow> &plan)
     // are short: about 20 000 pairs for the first, between four and twelve chunks.  Measured on config 2's pairs, host buffers to log10,
     // against one upload + one sweep: 30 000 pairs 0.57 -> 0.52 ms (1:2:2:1), 100 000 1.75 -> 1.12 (1:2:3:2:1), 300 000 4.71 -> 2.73,
     // 500 000 7.13 -> 4.32, 1 000 000 8.65 (seven chunks, one lane) -> 8.25 (twelve: 1:2:3:4:5:6:6:6:6:5:4:3; ten 8.37, sixteen 8.41).
+    // (Round 4, a slot per chunk: fourteen for the biggest batches, below.)
     unsigned C = (unsigned)std::min<uint64_t>(kMaxChunks, std::max<uint64_t>(4, n / kChunkTargetPairs));
     std::vector<unsigned> weight(C);
     {
         const unsigned P = (C + 1) / 2;  // plateau
         for (unsigned k = 0; k < C; ++k) weight[k] = std::min(std::min(k + 1, P), (C - k) + P / 2 - 1);
+    }
+    if (C == kMaxChunks && (!cross || b->n_reads >= 4096)) {  // (a cross product is cut by reads: with few of them the smallest chunk would be empty)
+        // the biggest batches begin with smaller steps still (5 000 pairs, then 2 : 4 : 8): the first sweep starts 0.15 ms into the call
+        // instead of 0.35, and with a slot per chunk the extra chunks cost nothing (round 4, configs 2 and 3: 0.1 ms per call, 1 %)
+        static const unsigned graded14[] = {1, 2, 4, 8, 12, 16, 20, 24, 24, 24, 24, 20, 16, 12};
+        C = 14;
+        weight.assign(graded14, graded14 + 14);
     }
     if (phmm_hook("PHMM_CHUNK_ONE_LANE") && C >= 7) {  // the plan of the one-lane form (A/B)
         static const unsigned graded7[] = {2, 6, 14, 26, 26, 18, 8};

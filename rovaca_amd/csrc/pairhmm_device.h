@@ -26,6 +26,18 @@ constexpr int kStripedRowsF64Min = 4, kStripedRowsF64Max = 6;
 // rows per lane of the band kernel (teams of several waves, fp32 and fp64 alike): measured on config 5, fp32 pass 4.7 ms at 8
 // rows, 3.6 at 6, 2.7 at 4; fp64 re-run 2 520 / 2 740 / 2 760 GCUPS overall at 6 / 5 / 4
 constexpr int kBandRows = 4;
+// Per type since round 4 (-DPHMM_BAND_ROWS_F32=n / -DPHMM_BAND_ROWS_F64=n are tuning hooks).  The fp32 pass of a long pair is one wave's
+// walk along the whole haplotype -- in fp32 nothing survives more than ~75 rows off the diagonal, so only the first stripe is ever full
+// width, and the pass lasts as long as that stripe's 12 000 dependent steps take -- and a step of two rows is shorter than one of
+// four: config 5's fp32 pass 2.42 ms at 4 rows per lane, 2.11 at 3, 2.04 at 2, 2.14 at 1 (profiles/r4_c5_band_rows.txt).  fp64, whose
+// full-width strip is ~1 000 rows deep and issue-bound, is fastest at 4 (pass 12.75 ms; 14.1 at 3, 15.1 at 2).
+#ifndef PHMM_BAND_ROWS_F32
+#define PHMM_BAND_ROWS_F32 2
+#endif
+#ifndef PHMM_BAND_ROWS_F64
+#define PHMM_BAND_ROWS_F64 kBandRows
+#endif
+constexpr int kBandRowsF32 = PHMM_BAND_ROWS_F32, kBandRowsF64 = PHMM_BAND_ROWS_F64;
 constexpr int kStripedGroupsPerBlock = 4;  // a team (1, 4 or 8 waves) of the striped kernel sweeps four pairs
 
 // 32-bit words per haplotype match plane (column j, 1-based, is bit 31-((j-1)&31) of word (j-1)>>5); one spare
@@ -74,7 +86,15 @@ struct KernelArgs
     // stripe), the first timeline_teams teams only; null otherwise.  Times are s_memrealtime ticks (100 MHz).
     unsigned long long *timeline;
     uint32_t timeline_teams;
+    // striped kernels, round 4: the rescue queue of a striped size range is a list IN PROCESSING ORDER with holes.  The fp32 launch
+    // writes an underflowed pair's id at the pair's own position of the launch (rescue_list[position], kNoPair elsewhere: the host fills
+    // the list before the pass) instead of appending it, and the fp64 launch strides over all n_pairs positions (n_pairs_dev only says
+    // whether there is anything at all) and skips the holes: the re-run then takes the pairs longest first, as the fp32 pass did,
+    // instead of in the order the fp32 teams happened to finish -- shortest first, the worst order for the makespan (config 5: fp64
+    // pass 10.4 -> 9.4 ms).  (At the end of the struct: the single-pass kernels' argument offsets are what they were.)
+    uint32_t sparse_order;
 };
+constexpr uint32_t kNoPair = 0xFFFFFFFFu;
 constexpr int kTimelineStripes = 64, kTimelineWords = 8;
 
 // lanes_per_pair 16: rows_per_lane = ceil(R / 16) in 1..kMaxRowsPerLane; 64: ceil(R / 64) in 1..kMaxRowsPerLaneWide

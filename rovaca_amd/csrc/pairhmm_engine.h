@@ -131,7 +131,7 @@ struct phmm_context
     // big one-shot batches are cut into chunks that go round three resident slots: chunk k is binned, packed and uploaded (on
     // side[2]) while chunk k - 1 is swept and chunk k - 2 is converted on the host by a collector thread (pairhmm_capi.cpp:
     // compute_chunked); the sums come back on a stream of their own so that the next sweep does not queue behind the copy
-    static constexpr int kChunkSlots = 6;
+    static constexpr int kChunkSlots = 16;  // (six until round 4: with a slot per chunk no chunk ever waits for an earlier one to be collected)
     struct phmm_resident *chunk_slot[kChunkSlots] = {};
     hipEvent_t chunk_up[kChunkSlots] = {}, chunk_swept[kChunkSlots] = {}, chunk_done[kChunkSlots] = {};
     hipStream_t down = nullptr;  // result copies of the chunked call
@@ -271,6 +271,7 @@ struct phmm_resident
     float *out32_host = nullptr;
     double *out64_host = nullptr;
     bool queue_is_empty = false;     // the set-up launch has just zeroed rescue_count
+    bool queue_sparse[phmm::kRescueQueues] = {};  // set by the fp32 pass: the queue is a list in processing order with holes (KernelArgs::sparse_order)
     DevBuf<float> carry32;
     DevBuf<double> carry64;
     std::vector<Bin> bins;

@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
     const uint32_t prev_wave = (uwave + WP - 1) % WP;
     T *wbase = carry + (static_cast<size_t>(team) * WP + uwave) * 3u * kGroups * carry_stride;
     const T *rbase = carry + (static_cast<size_t>(team) * WP + prev_wave) * 3u * kGroups * carry_stride;
-    const uint32_t n_pairs = a.n_rescue_queues ? 0u : a.n_pairs_dev ? *a.n_pairs_dev : a.n_pairs;  // uniform over the grid
+    // uniform over the grid (a list with holes, KernelArgs::sparse_order: all n_pairs positions unless nothing was queued)
+    const uint32_t n_pairs = a.n_rescue_queues ? 0u : a.n_pairs_dev ? (a.sparse_order ? (*a.n_pairs_dev ? a.n_pairs : 0u) : *a.n_pairs_dev) : a.n_pairs;
     uint32_t quads = (n_pairs + kGroups - 1) / kGroups;  // pairs are taken kGroups at a time
     uint32_t idle_at = 0;  // where a group without a pair of its own reads a VALID pair id: the first entry of a queue that has one
     for (uint32_t q = a.n_rescue_queues; q-- > 0;) {  // (several queues)
@@ -154,8 +155,12 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             }
         }
         const uint32_t gidx = quad * kGroups + grp;
-        const bool valid = gidx < q_pairs;
-        const uint32_t pair = a.order[valid ? q_base + gidx : idle_at];  // (one queue: idle_at = 0, its first entry)
+        bool valid = gidx < q_pairs;
+        uint32_t pair = a.order[valid ? q_base + gidx : idle_at];  // (one queue: idle_at = 0, its first entry)
+        if (a.sparse_order && a.n_pairs_dev) {  // the fp64 re-run over a list with holes: a hole is a group without a pair (pair 0 always exists)
+            valid = valid && pair != kNoPair;
+            pair = valid ? pair : 0u;
+        }
         const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
         const uint32_t R = a.read_len[r], H = a.hap_len[h];
         const uint32_t roff = a.read_off[r];
@@ -490,8 +495,10 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == G - 1) {
                         const T res = sumM + sumX;
                         reinterpret_cast<T *>(a.out_raw)[pair] = res;
-                        if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))
-                            a.rescue_list[atomicAdd(a.rescue_count, 1u)] = pair;
+                        if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f)) {
+                            const uint32_t at = atomicAdd(a.rescue_count, 1u);
+                            a.rescue_list[a.sparse_order ? gidx : at] = pair;  // (sparse_order: at the pair's own position of the launch)
+                        }
                     }
                 }
             }
@@ -558,7 +565,8 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
     const uint32_t prev_wave = (uwave + WP - 1) % WP;
     T *wbase = carry + (static_cast<size_t>(team) * WP + uwave) * 3u * kGroups * carry_stride;
     const T *rbase = carry + (static_cast<size_t>(team) * WP + prev_wave) * 3u * kGroups * carry_stride;
-    const uint32_t n_pairs = a.n_rescue_queues ? 0u : a.n_pairs_dev ? *a.n_pairs_dev : a.n_pairs;  // uniform over the grid
+    // uniform over the grid (a list with holes, KernelArgs::sparse_order: all n_pairs positions unless nothing was queued)
+    const uint32_t n_pairs = a.n_rescue_queues ? 0u : a.n_pairs_dev ? (a.sparse_order ? (*a.n_pairs_dev ? a.n_pairs : 0u) : *a.n_pairs_dev) : a.n_pairs;
     uint32_t quads = (n_pairs + kGroups - 1) / kGroups;  // pairs are taken kGroups at a time
     uint32_t idle_at = 0;  // where a group without a pair of its own reads a VALID pair id: the first entry of a queue that has one
     for (uint32_t q = a.n_rescue_queues; q-- > 0;) {  // (several queues)
@@ -582,8 +590,12 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             }
         }
         const uint32_t gidx = quad * kGroups + grp;
-        const bool valid = gidx < q_pairs;
-        const uint32_t pair = a.order[valid ? q_base + gidx : idle_at];  // (one queue: idle_at = 0, its first entry)
+        bool valid = gidx < q_pairs;
+        uint32_t pair = a.order[valid ? q_base + gidx : idle_at];  // (one queue: idle_at = 0, its first entry)
+        if (a.sparse_order && a.n_pairs_dev) {  // the fp64 re-run over a list with holes: a hole is a group without a pair (pair 0 always exists)
+            valid = valid && pair != kNoPair;
+            pair = valid ? pair : 0u;
+        }
         const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
         const uint32_t R = a.read_len[r], H = a.hap_len[h];
         const uint32_t roff = a.read_off[r];
@@ -965,8 +977,10 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             if (valid && lane == G - 1) {
                 const T res = sumM + sumX;
                 reinterpret_cast<T *>(a.out_raw)[pair] = res;
-                if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f))
-                    a.rescue_list[atomicAdd(a.rescue_count, 1u)] = pair;
+                if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f)) {
+                    const uint32_t at = atomicAdd(a.rescue_count, 1u);
+                    a.rescue_list[a.sparse_order ? gidx : at] = pair;  // (sparse_order: at the pair's own position of the launch)
+                }
             }
         };
 
@@ -1211,8 +1225,8 @@ hipError_t launch_striped_f32(bool uniform_gcp, int waves_per_team, int lanes_pe
                               uint32_t carry_stride, uint32_t teams, hipStream_t s)
 {
     if (waves_per_team == 1) return launch_team_w<float, kStripedRowsF32, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
-    if (waves_per_team == 4) return launch_team_w<float, kBandRows, 4>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
-    if (waves_per_team == 8) return launch_team_w<float, kBandRows, 8>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team == 4) return launch_team_w<float, kBandRowsF32, 4>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team == 8) return launch_team_w<float, kBandRowsF32, 8>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
     return hipErrorInvalidValue;
 }
 
@@ -1221,8 +1235,8 @@ hipError_t launch_striped_f64(int rows_per_lane, bool uniform_gcp, int waves_per
 {
     static_assert(kStripedRowsF64Min == 4 && kStripedRowsF64Max == 6, "instantiate every rows-per-lane value in the range");
     // several waves per team: kBandRows rows per lane whatever was asked for (see launch_team_w)
-    if (waves_per_team == 4) return launch_team_w<double, kBandRows, 4>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
-    if (waves_per_team == 8) return launch_team_w<double, kBandRows, 8>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team == 4) return launch_team_w<double, kBandRowsF64, 4>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
+    if (waves_per_team == 8) return launch_team_w<double, kBandRowsF64, 8>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
     if (waves_per_team != 1) return hipErrorInvalidValue;
     if (rows_per_lane == 4) return launch_team_w<double, 4, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);
     if (rows_per_lane == 5) return launch_team_w<double, 5, 1>(uniform_gcp, lanes_per_pair, a, carry, carry_stride, teams, s);

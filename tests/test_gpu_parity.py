@@ -315,6 +315,47 @@ def test_team_kernel_every_width(engine, waves, lanes, monkeypatch):
     _check_against_oracle(engine, Batch.from_lists(reads, haps, pairs))
 
 
+@pytest.mark.parametrize("lanes", [16, 64])
+@pytest.mark.parametrize("waves", [1, 4])
+def test_striped_rescue_list_in_processing_order_with_holes(engine, waves, lanes, monkeypatch):
+    # The rescue queue of a striped size range is a list in processing order: the fp32 launch writes an underflowed pair's id at the
+    # pair's own position, the fp64 launch walks every position and skips the holes (KernelArgs::sparse_order; PHMM_RESCUE_APPEND=1 is
+    # the appended list of rounds 1-3).  Long reads of which only some underflow -- clean ones among noisy ones, in no particular order
+    # -- must give the oracle's bits in both forms, for one wave per team and for the band kernel, four pairs per wave and one,
+    # and a batch of long reads none of which underflows must launch a re-run that finds nothing.
+    monkeypatch.setenv("PHMM_FORCE_TEAM_WAVES", str(waves))
+    monkeypatch.setenv("PHMM_FORCE_TEAM_LANES", str(lanes))
+    rng = np.random.default_rng(77 + waves + lanes)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    reads, haps, pairs = [], [], []
+    for i in range(22):
+        R, H = int(rng.integers(520, 1400)), int(rng.integers(1500, 2600))
+        hap = acgt[rng.integers(0, 4, H)]
+        st = int(rng.integers(0, H - R + 1))
+        seq = hap[st:st + R].copy()
+        noisy = i % 3 != 1
+        if noisy:
+            sub = rng.random(R) < 0.04
+            seq[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        q = np.full(R, 37, np.uint8) if not noisy else rng.choice(np.array([11, 25, 37], np.uint8), R, p=[0.1, 0.2, 0.7])
+        g = np.full(R, 45, np.uint8)
+        reads.append((seq, q, g, g, np.full(R, 10, np.uint8)))
+        haps.append(hap)
+        pairs.append((i, i))
+    pairs += [(1, 0), (4, 4), (7, 6), (10, 10), (13, 2)]
+    b = Batch.from_lists(reads, haps, pairs)
+    raw, l10 = _check_against_oracle(engine, b)
+    resc = raw < np.float32(1e-28)
+    assert 5 < int(resc.sum()) < b.n_pairs - 5  # holes and entries both
+    monkeypatch.setenv("PHMM_RESCUE_APPEND", "1")
+    araw, al10, ast = engine.compute(b)
+    monkeypatch.delenv("PHMM_RESCUE_APPEND")
+    assert np.array_equal(araw.view(np.uint32), raw.view(np.uint32)) and np.array_equal(al10, l10)
+    clean = np.flatnonzero(~resc)
+    craw, cl10, cst = engine.compute(b.subset(clean))
+    assert int(cst.n_rescued) == 0 and np.array_equal(cl10, l10[clean])
+
+
 @pytest.mark.parametrize("wide_single_pass", [True, False])
 def test_reads_of_257_to_512_bases(engine, wide_single_pass, monkeypatch):
     # still one pass with a whole wave per pair (K = ceil(R/64) up to 8), or the team kernel when that is switched off
