@@ -230,6 +230,8 @@ void phmm_release(phmm_context *c, phmm_resident *rb)
 // pinned staging buffer, bin the pairs -- and touches nothing of the context but the device number, so the chunk pipeline of a big
 // one-shot call runs it for several chunks at once on worker threads (pairhmm_chunked.cpp).  upload_enqueue is the HIP side: one copy,
 // the views into the blob, the device buffers, the set-up launch; the pipeline keeps it on one thread, in chunk order.
+static void harvest_history(phmm_context *c, phmm_resident *rb);
+
 int upload_prepare(phmm_context *c, const phmm_batch *b, phmm_resident *rb, const UploadOpts &opt, phmm_detail::BinScratch &bin_scratch)
 {
     if ((b->pair_read == nullptr) != (b->pair_hap == nullptr))
@@ -379,6 +381,9 @@ int upload_prepare(phmm_context *c, const phmm_batch *b, phmm_resident *rb, cons
     // ---- pair list (materialise the cross product) and length binning: pairhmm_binning.cpp ----
     uint64_t cells = 0;
     {
+        harvest_history(c, rb);  // (the batch this slot held before: what its last pass saw goes into the context's history)
+        for (int qi = 0; qi < kQueues; ++qi) rb->f64_share_known[qi] = rb->queue_f64_first[qi] = false;  // a new batch: the context's history decides its first pass
+        rb->hist_pending = false;
         rb->ragged = ragged_launches_for(ug);  // the classes share launches: no need for small ones to ride along at more rows per lane
         const int rc = phmm_detail::bin_pairs(b, cross, n_pairs, opt.read_bias, opt.hap_bias, pr, ph, order, bin_scratch, rb->bins, &cells,
                                               !rb->ragged);
@@ -652,18 +657,36 @@ int phmm_upload(phmm_context *c, const phmm_batch *b, phmm_resident **out)
     return PHMM_OK;
 }
 
+// fp64 first (sweep_fp32): what the batch's last finished pass observed on its striped ranges, if the counters are back
+static void harvest_history(phmm_context *c, phmm_resident *rb)
+{
+    if (!rb->hist_pending || hipEventQuery(rb->hist_ready) != hipSuccess) return;
+    const uint32_t *cnt = static_cast<const uint32_t *>(rb->hist_host.p);
+    uint64_t all = 0, all_by_f64 = 0;
+    for (int qi = 1; qi <= 4; ++qi) {
+        if (!rb->hist_cap[qi]) continue;
+        // fp32 first: the counter is the number of underflowed pairs; fp64 first: the number sent on to the fp32 kernel
+        const uint32_t by_f64 = rb->hist_f64_first[qi] ? rb->hist_cap[qi] - std::min(cnt[qi], rb->hist_cap[qi]) : std::min(cnt[qi], rb->hist_cap[qi]);
+        rb->f64_share[qi] = (float)by_f64 / (float)rb->hist_cap[qi];
+        rb->f64_share_known[qi] = true;
+        all += rb->hist_cap[qi];
+        all_by_f64 += by_f64;
+    }
+    if (all) {
+        c->f64_share = (float)all_by_f64 / (float)all;
+        c->f64_share_known = true;
+    }
+    rb->hist_pending = false;
+}
+
 int sweep_fp32(phmm_context *c, phmm_resident *rb)
 {
     if (rb->n_pairs && !rb->queue_is_empty) HIP_TRY(hipMemsetAsync(rb->rescue_count.p, 0, kQueues * sizeof(uint32_t), c->stream));
     rb->queue_is_empty = false;
     // striped launches run side by side on different streams: each gets its own slice of the carry buffer, sized up front
-    struct StripedPlan
-    {
-        TeamShape sh;
-        uint32_t teams;
-        size_t carry_at;
-    };
-    std::vector<StripedPlan> plans(rb->bins.size());
+    using StripedPlan = phmm_resident::StripedLaunchPlan;
+    std::vector<StripedPlan> &plans = rb->fp32_plans;  // (kept: an fp64-first range launches its fp32 kernel from sweep_rescue)
+    plans.assign(rb->bins.size(), StripedPlan());
     size_t carry_total = 0;
     for (size_t i = 0; i < rb->bins.size(); ++i) {
         const Bin &bin = rb->bins[i];
@@ -689,9 +712,48 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         if (bin.queue >= 1 && bin.queue <= 4 && in_place && striped_kernel_bin(bin)) rb->queue_sparse[bin.queue] = true;
     for (const Bin &bin : rb->bins)
         if (bin.queue >= 1 && bin.queue <= 4 && !striped_kernel_bin(bin)) rb->queue_sparse[bin.queue] = false;  // (a queue is fed one way)
-    for (const Bin &bin : rb->bins)
-        if (rb->queue_sparse[bin.queue])
-            HIP_TRY(hipMemsetAsync(rb->rescue_list.p + bin.first, 0xFF, (size_t)bin.count * sizeof(uint32_t), c->stream));
+    // ---- fp64 first ----
+    // A striped range whose pairs all underflow fp32 -- reads of thousands of bases with ordinary error rates: config 5, every pair --
+    // pays for an fp32 pass that decides nothing (config 5: 2.0 of 11.1 ms).  When the last pass over such a range has seen at least
+    // kF64FirstShare of its pairs decided by fp64, this pass runs fp64 FIRST, over every pair of the range, and the fp32 kernel only for
+    // the pairs whose fp64 sum says fp32 might NOT underflow.  The decision per pair is still the reference's, "fp32 sum < 1e-28f":
+    //   * every quantity of the recurrence is non-negative, so the fp32 evaluation can exceed the exact value of the same expression
+    //     only by rounding: (1 + 2^-24) per operation along the longest dependence chain, at most 4 (R + H) operations -- 1.06 for
+    //     R + H = 2^18, the longest pair that goes this way; flush-to-zero only lowers it.  The fp32 tables differ from the fp64 ones
+    //     by at most 1e-6 per factor (pairhmm_tables.cpp: the same Jacobian-log index in both types, one float rounding of the sum and
+    //     one of the entry; powf against pow), 3 factors per cell of a path: (1 + 1e-6)^(3 * 2^18) = 2.2.  The fp64 sum carries 1e-12.
+    //   * so fp32_sum <= 2^-900 * fp64_sum * 2.4 (the scales are 2^120 and 2^1020), and a pair with
+    //     2^-900 * fp64_sum < 1e-28 * 2^-20 underflows fp32 with five decades to spare: its answer is the fp64 one, and its fp32 sum is
+    //     REPORTED as 0 (the reference discards it: pairhmm_internal.cpp:577-585).  Every other pair gets its fp32 sum from the fp32
+    //     kernel and is decided by it, exactly as in the fp32-first order.
+    // Same answers either way (tests: both orders forced, pairs on both sides of the threshold and in the margin); what changes is
+    // which kernel runs needlessly when the guess is wrong -- fp64-first on a range whose pairs do not underflow costs the fp64 pass,
+    // 4-5x an fp32 one, once: the next pass sees the share and goes back.  PHMM_F64_FIRST=0 / 1 (test hook): never / always.
+    // Only where the sums land in device memory (resident batches and the plain one-shot call), since the skipped pairs' fp32 sums
+    // are zeroed by a memset.
+    constexpr float kF64FirstShare = 0.75f;
+    {
+        // what the last finished pass observed (the counters come back behind the pass, asynchronously)
+        harvest_history(c, rb);
+        int forced = -1;
+        if (const char *f = phmm_hook("PHMM_F64_FIRST")) forced = atoi(f) ? 1 : 0;
+        for (int qi = 0; qi < kQueues; ++qi) rb->queue_f64_first[qi] = false;
+        for (const Bin &bin : rb->bins) {
+            const int qi = bin.queue;
+            if (!(qi >= 1 && qi <= 4) || !rb->queue_sparse[qi] || rb->out32_host) continue;
+            if ((uint64_t)bin.max_read_len + bin.max_hap_len > (1u << 18)) continue;  // (the bound above is argued with room to spare up to here)
+            const bool known = rb->f64_share_known[qi] || c->f64_share_known;
+            const float share = rb->f64_share_known[qi] ? rb->f64_share[qi] : c->f64_share;
+            rb->queue_f64_first[qi] = forced >= 0 ? forced == 1 : (known && share >= kF64FirstShare);
+        }
+    }
+    bool any_f64_first = false;
+    for (const Bin &bin : rb->bins) {
+        if (!rb->queue_sparse[bin.queue]) continue;
+        HIP_TRY(hipMemsetAsync(rb->rescue_list.p + bin.first, 0xFF, (size_t)bin.count * sizeof(uint32_t), c->stream));
+        any_f64_first = any_f64_first || rb->queue_f64_first[bin.queue];
+    }
+    if (any_f64_first) HIP_TRY(hipMemsetAsync(rb->raw32.p, 0, (size_t)rb->n_pairs * sizeof(float), c->stream));  // (before any launch of the pass)
     // The launches of the pass.  A striped bin is one launch.  Single-pass bins are one launch each too -- unless the batch takes ragged
     // launches (the Rovaca case; pairhmm_kernels_ragged.hip): then a run of single-pass bins is cut into the K ranges that share a
     // kernel and every range with more than one bin is ONE launch whose workgroups pick their class's K, longest rows first.
@@ -713,6 +775,10 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
     auto wide_rows = [](const Bin &b) { return (int)((b.max_read_len + 63) / 64); };  // rows per lane at one pair per wave
     std::vector<FpLaunch> launches;
     for (size_t i = 0; i < rb->bins.size();) {
+        if (rb->queue_f64_first[rb->bins[i].queue]) {  // (sweep_rescue launches both of its kernels)
+            ++i;
+            continue;
+        }
         if (!(rb->ragged && rb->bins[i].rows_per_lane > 0)) {
             launches.push_back(FpLaunch{i, 1, 0});
             ++i;
@@ -980,7 +1046,19 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
         a.pair_read = rb->pair_read.p;
         a.pair_hap = rb->pair_hap.p;
         a.n_pairs = 0;
-        if (L.queues.size() == 1) {
+        const bool f64_first = L.queues.size() == 1 && rb->queue_f64_first[L.queues[0]];
+        if (f64_first) {
+            // fp64 FIRST (sweep_fp32): every pair of the range, in processing order; the pairs whose sum says fp32 might not underflow
+            // are queued for the fp32 kernel below, at their own positions
+            const int qi = L.queues[0];
+            a.order = rb->order.p + q[qi].base;
+            a.n_pairs = q[qi].cap;
+            a.sparse_order = 1;
+            a.rescue_list = rb->rescue_list.p + q[qi].base;
+            a.rescue_count = rb->rescue_count.p + qi;
+            a.need32_above = std::ldexp(1e-28, 900 - 20);
+        }
+        else if (L.queues.size() == 1) {
             const int qi = L.queues[0];
             a.order = rb->rescue_list.p + q[qi].base;
             a.n_pairs_dev = rb->rescue_count.p + qi;
@@ -1017,6 +1095,31 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
         }
         HIP_TRY(phmm::launch_striped_f64(L.rows, rb->uniform_gcp, L.sh.waves, L.sh.lanes, a, rb->carry64.p + L.carry_at, L.max_hap + 1,
                                          L.teams, st));
+        if (f64_first) {
+            // the fp32 kernel over the queued pairs (usually none: its teams read the count and leave), behind the fp64 launch
+            const int qi = L.queues[0];
+            for (size_t i = 0; i < rb->bins.size(); ++i) {
+                const Bin &bin = rb->bins[i];
+                if (bin.queue != qi || i >= rb->fp32_plans.size()) continue;
+                const phmm_resident::StripedLaunchPlan &pl = rb->fp32_plans[i];
+                phmm::KernelArgs b = a;
+                b.order = rb->rescue_list.p + bin.first;
+                b.n_pairs = bin.count;
+                b.n_pairs_dev = rb->rescue_count.p + qi;
+                b.sparse_order = 1;
+                b.rescue_list = nullptr;
+                b.rescue_count = nullptr;
+                b.need32_above = 0.0;
+                b.timeline = nullptr;
+                b.timeline_teams = 0;
+                b.lds_words_per_group = bin.lds_words_per_group;
+                b.ph2pr = c->ph2pr_f32.p;
+                b.mm_table = c->mm_f32.p;
+                b.out_raw = rb->raw32.p;
+                HIP_TRY(phmm::launch_striped_f32(rb->uniform_gcp, pl.sh.waves, pl.sh.lanes, b, rb->carry32.p + pl.carry_at, bin.max_hap_len + 1,
+                                                 pl.teams, st));
+            }
+        }
         if (tl_path) {
             std::vector<unsigned long long> h(tl_n);
             HIP_TRY(hipStreamSynchronize(st));
@@ -1042,6 +1145,21 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
             HIP_TRY(hipEventRecord(s_join[i], s_side[i]));
             HIP_TRY(hipStreamWaitEvent(s_main, s_join[i], 0));
         }
+    }
+    // what this pass observed on its striped ranges, for the next one's choice of order (sweep_fp32, "fp64 first"): the counters come
+    // back behind the pass, nobody waits for them
+    bool observe = false;
+    for (int qi = 1; qi <= 4; ++qi) observe = observe || (rb->queue_sparse[qi] && q[qi].cap && !rb->out32_host);
+    if (observe) {
+        HIP_TRY(rb->hist_host.ensure(kQueues * sizeof(uint32_t)));
+        if (!rb->hist_ready) HIP_TRY(hipEventCreateWithFlags(&rb->hist_ready, hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(rb->hist_host.p, rb->rescue_count.p, kQueues * sizeof(uint32_t), hipMemcpyDeviceToHost, s_main));
+        HIP_TRY(hipEventRecord(rb->hist_ready, s_main));
+        for (int qi = 0; qi < kQueues; ++qi) {
+            rb->hist_cap[qi] = qi >= 1 && qi <= 4 && rb->queue_sparse[qi] ? q[qi].cap : 0u;
+            rb->hist_f64_first[qi] = rb->queue_f64_first[qi];
+        }
+        rb->hist_pending = true;
     }
     return PHMM_OK;
 }
@@ -1113,7 +1231,10 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
     if (c->cpu) return cpu_download(c, rb, out_raw_f32, out_log10, stats);
     HIP_TRY(hipSetDevice(c->device));
     const uint64_t n = rb->n_pairs;
-    const bool want = (out_raw_f32 || out_log10) && n;
+    // (a range that ran fp64 first has no count of underflowed pairs on the device: they are counted here, on the fp32 sums)
+    bool any_f64_first = false;
+    for (int qi = 1; qi <= 4; ++qi) any_f64_first = any_f64_first || rb->queue_f64_first[qi];
+    const bool want = ((out_raw_f32 || out_log10) && n) || (any_f64_first && n);
     // results come back through pinned staging: [n floats, padding, rescue count][n doubles when anything was rescued]
     const size_t count_at = (n + 63) & ~size_t(63);
     const size_t off_cnt = count_at * sizeof(float);
@@ -1132,7 +1253,15 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
     if (n) {
         const uint32_t *counts = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(rb->out_stage.p) + off_cnt);
         rb->last_rescued = 0;
-        for (int qi = 0; qi < kQueues; ++qi) rb->last_rescued += counts[qi];
+        for (int qi = 0; qi < kQueues; ++qi)
+            if (!rb->queue_f64_first[qi]) rb->last_rescued += counts[qi];
+        if (any_f64_first) {
+            const float *rp = static_cast<const float *>(rb->out_stage.p);
+            const uint32_t *order_h = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(rb->stage.p) + rb->plan.o_order);
+            for (const Bin &bin : rb->bins)
+                if (rb->queue_f64_first[bin.queue])
+                    for (uint32_t i = 0; i < bin.count; ++i) rb->last_rescued += rp[order_h[bin.first + i]] < PHMM_MIN_ACCEPTED_F32 ? 1u : 0u;
+        }
     }
     const bool want64 = out_log10 && rb->last_rescued && n;
     if (want64) {

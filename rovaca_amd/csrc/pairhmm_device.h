@@ -93,6 +93,10 @@ struct KernelArgs
     // instead of in the order the fp32 teams happened to finish -- shortest first, the worst order for the makespan (config 5: fp64
     // pass 10.4 -> 9.4 ms).  (At the end of the struct: the single-pass kernels' argument offsets are what they were.)
     uint32_t sparse_order;
+    // fp64 FIRST (round 4, striped ranges whose pairs have been underflowing fp32: pairhmm_capi.cpp, "fp64 first"): an fp64 launch over
+    // ALL pairs of the range with rescue_list set queues -- at the pair's position, sparse_order -- every pair whose sum is at least
+    // need32_above: the pairs whose fp32 sum might reach 1e-28, for which the fp32 kernel then runs and decides as the reference does
+    double need32_above;
 };
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;
 constexpr int kTimelineStripes = 64, kTimelineWords = 8;

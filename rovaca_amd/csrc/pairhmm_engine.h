@@ -128,6 +128,10 @@ struct phmm_context
     hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[kSideStreams] = {nullptr, nullptr, nullptr};
     struct phmm_resident *scratch = nullptr;  // reused by phmm_compute: device buffers survive between calls
+    // fp64 first: the share of long pairs (striped ranges) that fp64 decided in the last pass any batch of this context finished --
+    // what a new batch's first pass goes by
+    float f64_share = 0.f;
+    bool f64_share_known = false;
     // big one-shot batches are cut into chunks that go round three resident slots: chunk k is binned, packed and uploaded (on
     // side[2]) while chunk k - 1 is swept and chunk k - 2 is converted on the host by a collector thread (pairhmm_capi.cpp:
     // compute_chunked); the sums come back on a stream of their own so that the next sweep does not queue behind the copy
@@ -248,7 +252,11 @@ struct phmm_resident
 {
     UploadPlan plan;
     CpuBatch *cpu = nullptr;
-    ~phmm_resident() { delete cpu; }
+    ~phmm_resident()
+    {
+        delete cpu;
+        if (hist_ready) (void)hipEventDestroy(hist_ready);
+    }
     uint64_t n_pairs = 0, cells = 0;
     uint32_t n_reads = 0, n_haps = 0, max_hap_len = 0, max_read_len = 0;
     bool uniform_gcp = false, uniform_gop = false;
@@ -271,6 +279,22 @@ struct phmm_resident
     float *out32_host = nullptr;
     double *out64_host = nullptr;
     bool queue_is_empty = false;     // the set-up launch has just zeroed rescue_count
+    // fp64 first (pairhmm_capi.cpp): striped ranges whose fp32 pass is skipped this pass; what the last finished pass observed per
+    // striped queue (pairs, of which fp64 decided), read back asynchronously into `hist_host` behind `hist_ready`
+    bool queue_f64_first[phmm::kRescueQueues] = {};
+    struct StripedLaunchPlan
+    {
+        TeamShape sh{16, 1};
+        uint32_t teams = 0;
+        size_t carry_at = 0;
+    };
+    std::vector<StripedLaunchPlan> fp32_plans;  // per bin (striped bins only), made by the fp32 pass
+    HostBuf hist_host;
+    hipEvent_t hist_ready = nullptr;
+    bool hist_pending = false, hist_f64_first[phmm::kRescueQueues] = {};
+    uint32_t hist_cap[phmm::kRescueQueues] = {};
+    float f64_share[phmm::kRescueQueues] = {};  // share of a striped queue's pairs that fp64 decided, as last observed ...
+    bool f64_share_known[phmm::kRescueQueues] = {};  // ... if at all
     bool queue_sparse[phmm::kRescueQueues] = {};  // set by the fp32 pass: the queue is a list in processing order with holes (KernelArgs::sparse_order)
     DevBuf<float> carry32;
     DevBuf<double> carry64;

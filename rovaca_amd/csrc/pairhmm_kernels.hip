@@ -495,7 +495,8 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     if (c + 1 == Bs && v + 1 == max_stripes && valid && lane == G - 1) {
                         const T res = sumM + sumX;
                         reinterpret_cast<T *>(a.out_raw)[pair] = res;
-                        if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f)) {
+                        // fp32: underflowed, to the fp64 re-run; fp64 (only the fp64-first launch has a list): fp32 might not underflow
+                        if (a.rescue_list && (sizeof(T) == 4 ? res < static_cast<T>(1e-28f) : static_cast<double>(res) >= a.need32_above)) {
                             const uint32_t at = atomicAdd(a.rescue_count, 1u);
                             a.rescue_list[a.sparse_order ? gidx : at] = pair;  // (sparse_order: at the pair's own position of the launch)
                         }
@@ -977,7 +978,8 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             if (valid && lane == G - 1) {
                 const T res = sumM + sumX;
                 reinterpret_cast<T *>(a.out_raw)[pair] = res;
-                if (sizeof(T) == 4 && a.rescue_list && res < static_cast<T>(1e-28f)) {
+                // fp32: underflowed, to the fp64 re-run; fp64 (only the fp64-first launch has a list): fp32 might not underflow
+                if (a.rescue_list && (sizeof(T) == 4 ? res < static_cast<T>(1e-28f) : static_cast<double>(res) >= a.need32_above)) {
                     const uint32_t at = atomicAdd(a.rescue_count, 1u);
                     a.rescue_list[a.sparse_order ? gidx : at] = pair;  // (sparse_order: at the pair's own position of the launch)
                 }

@@ -356,6 +356,109 @@ def test_striped_rescue_list_in_processing_order_with_holes(engine, waves, lanes
     assert int(cst.n_rescued) == 0 and np.array_equal(cl10, l10[clean])
 
 
+def _long_reads_around_the_fp32_threshold(seed, n_per_step=2):
+    # reads of 600-1300 bases with exactly m substitutions at Q37, m = 6 ... 26: about 4.2 decades per substitution, so the fp32 sums
+    # (scale 2^120 = 1.3e36, accepted from 1e-28) run from comfortably accepted through the threshold to flushed to zero
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    reads, haps, pairs = [], [], []
+    for m in range(6, 27):
+        for _ in range(n_per_step):
+            R, H = int(rng.integers(600, 1300)), int(rng.integers(1400, 2400))
+            hap = acgt[rng.integers(0, 4, H)]
+            st = int(rng.integers(0, H - R + 1))
+            seq = hap[st:st + R].copy()
+            at = rng.choice(R, m, replace=False)
+            seq[at] = acgt[(np.searchsorted(acgt, seq[at]) + rng.integers(1, 4, m)) % 4]
+            g = np.full(R, 45, np.uint8)
+            reads.append((seq, np.full(R, 37, np.uint8), g, g, np.full(R, 10, np.uint8)))
+            haps.append(hap)
+            pairs.append((len(reads) - 1, len(haps) - 1))
+    order = rng.permutation(len(pairs))
+    return Batch.from_lists(reads, haps, [pairs[i] for i in order])
+
+
+@pytest.mark.parametrize("lanes", [16, 64])
+@pytest.mark.parametrize("waves", [1, 4])
+def test_fp64_first_decides_every_pair_as_fp32_first_does(engine, waves, lanes, monkeypatch):
+    # A range of long pairs that has been underflowing is swept fp64 FIRST (every pair), and the fp32 kernel then runs only for the
+    # pairs whose fp64 sum says fp32 might not underflow (pairhmm_capi.cpp, "fp64 first"); PHMM_F64_FIRST=1 / 0 force the order.  Pairs
+    # on both sides of the fp32 threshold and close to it: the log10 likelihoods, the set of re-run pairs and the fp32 sums of the
+    # accepted pairs are bit for bit those of the fp32-first order and the oracle's; the fp32 sum of a pair that provably underflows is
+    # reported as 0.
+    monkeypatch.setenv("PHMM_FORCE_TEAM_WAVES", str(waves))
+    monkeypatch.setenv("PHMM_FORCE_TEAM_LANES", str(lanes))
+    b = _long_reads_around_the_fp32_threshold(300 + waves + lanes)
+    monkeypatch.setenv("PHMM_F64_FIRST", "0")
+    raw, l10 = _check_against_oracle(engine, b)
+    resc = raw < np.float32(1e-28)
+    assert 8 < int(resc.sum()) < b.n_pairs - 8
+    assert ((raw > 0) & resc).any()  # the margin: underflowed, but not to zero
+    monkeypatch.setenv("PHMM_F64_FIRST", "1")
+    for _ in range(2):
+        fraw, fl10, fst = engine.compute(b)
+        assert np.array_equal(fl10, l10)
+        assert np.array_equal(fraw[~resc].view(np.uint32), raw[~resc].view(np.uint32))
+        assert (fraw[resc] < np.float32(1e-28)).all() and int(fst.n_rescued) == int(resc.sum())
+        assert ((fraw[resc] == raw[resc]) | (fraw[resc] == 0)).all() and (fraw[resc] == 0).any()
+    # resident: the two orders in turn on one uploaded batch
+    rb = engine.upload(b)
+    try:
+        for first in ("1", "0", "1"):
+            monkeypatch.setenv("PHMM_F64_FIRST", first)
+            rb.sweep()
+            rraw, rl10, rst = rb.download()
+            assert np.array_equal(rl10, l10) and int(rst.n_rescued) == int(resc.sum())
+            assert np.array_equal(rraw[~resc].view(np.uint32), raw[~resc].view(np.uint32))
+    finally:
+        rb.release()
+
+
+def test_fp64_first_is_chosen_by_what_the_last_pass_saw(monkeypatch):
+    # the default (no hook): a batch's first pass is fp32 first; when at least three quarters of a striped range underflowed, the next
+    # pass over it runs fp64 first (the fp32 phase of the pass all but disappears), and a new batch in the same context starts from
+    # what the context has seen; a range of clean long reads stays fp32 first.  Same answers throughout.
+    monkeypatch.delenv("PHMM_F64_FIRST")
+    eng = capi.Engine(0)
+    try:
+        noisy = synth.make_batch(seed=95, n_regions=3, reads=6, haps=4, read_len=(1500, 3000), hap_len=(3200, 4200), sub_rate=0.02)
+        rb = eng.upload(noisy)
+        ms1, ms32_1 = rb.sweep_timed(1)
+        raw1, l10_1, st1 = rb.download()
+        assert int(st1.n_rescued) == noisy.n_pairs
+        ms2, ms32_2 = rb.sweep_timed(1)
+        raw2, l10_2, st2 = rb.download()
+        assert np.array_equal(l10_1, l10_2) and int(st2.n_rescued) == noisy.n_pairs and (raw2 == 0).all()
+        assert ms32_2 < 0.5 * ms32_1, (ms32_1, ms32_2)
+        rb.release()
+        # a new batch of the same kind: fp64 first from its first pass
+        noisy2 = synth.make_batch(seed=96, n_regions=3, reads=6, haps=4, read_len=(1500, 3000), hap_len=(3200, 4200), sub_rate=0.02)
+        rb = eng.upload(noisy2)
+        ms3, ms32_3 = rb.sweep_timed(1)
+        raw3, l10_3, st3 = rb.download()
+        rb.release()
+        assert ms32_3 < 0.5 * ms32_1, (ms32_1, ms32_3)
+        monkeypatch.setenv("PHMM_F64_FIRST", "0")
+        _, ref3, _ = eng.compute(noisy2)
+        monkeypatch.delenv("PHMM_F64_FIRST")
+        assert np.array_equal(l10_3, ref3)
+        # clean long reads: the guess from the context's history is wrong once (fp64 first, every pair sent on to the fp32 kernel), the
+        # next pass is fp32 first again; the answers never change
+        clean = synth.make_batch(seed=97, n_regions=3, reads=6, haps=4, read_len=(1500, 3000), hap_len=(3200, 4200), sub_rate=0.0, qual=40)
+        rb = eng.upload(clean)
+        outs = []
+        for _ in range(3):
+            rb.sweep()
+            outs.append(rb.download())
+        rb.release()
+        assert all(int(o[2].n_rescued) == 0 for o in outs)
+        assert all(np.array_equal(o[1], outs[0][1]) and np.array_equal(o[0].view(np.uint32), outs[0][0].view(np.uint32)) for o in outs)
+        oraw, ol10, oresc = oracle.batch(clean, n_threads=8)
+        assert not oresc.any() and np.array_equal(outs[0][0].view(np.uint32), oraw.view(np.uint32)) and np.array_equal(outs[0][1], ol10)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("wide_single_pass", [True, False])
 def test_reads_of_257_to_512_bases(engine, wide_single_pass, monkeypatch):
     # still one pass with a whole wave per pair (K = ceil(R/64) up to 8), or the team kernel when that is switched off

@@ -21,13 +21,18 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES"; do
   echo "pmc (general kernel) $grp done"
 done
 unset PHMM_NO_UNIFORM_GOP PHMM_ENABLE_TEST_HOOKS
-# configs 3 and 5: instruction counts and traffic per pass (bench.py --config c3 / c5 price their lines with them)
+# configs 3 and 5: instruction counts and traffic per pass (bench.py --config c3 / c5 price their lines with them).  Config 5 with the
+# reference's order of passes forced (PHMM_F64_FIRST=0: fp32 kernel, then fp64 for what underflowed -- every pair), so that "per pass"
+# means one real launch of each kernel; by default the passes after the first run the fp64 kernel first and an empty fp32 launch (the
+# kernel traces above are of the default).  The fp64 kernel does the same work either way.
+export PHMM_ENABLE_TEST_HOOKS=1 PHMM_F64_FIRST=0
 for c in c3 c5; do
 for grp in "SQ_INSTS_VALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc${c}_$tag -o pmc -- python3 bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/pmc${c}_$tag.log 2>&1
   echo "pmc $c $grp done"
 done; done
+unset PHMM_ENABLE_TEST_HOOKS PHMM_F64_FIRST
 find $OUT -name "*.csv" | head -30
 # Smith-Waterman aligner: kernel trace of bench.py --config sw
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sw -o sw -- python3 bench.py --config sw --no-cpu-baseline > $OUT/bench_sw.log 2>&1
