@@ -112,7 +112,10 @@ const char *phmm_last_error(void); /* thread-local text of the last failure */
 
 /* ---- one-shot: host buffers in, host buffers out.
  * out_log10[p] = raw >= 1e-28f ? (double)(log10f(raw) - 36.1236000061f) : log10(raw64) - 307.050595577260822
- * (pairhmm_internal.cpp:577-585); out_raw_f32 (nullable) receives the fp32 sums the first pass produced.
+ * (pairhmm_internal.cpp:577-585); out_raw_f32 (nullable) receives the fp32 sums: for a pair decided by fp32 (>= 1e-28f) the sum the
+ * reference's fp32 kernel gives, bit for bit; for a pair decided by fp64 a value below 1e-28f -- that same fp32 sum, or 0 where the
+ * library established the underflow from the fp64 sum without running the fp32 kernel (long reads that keep underflowing are swept
+ * fp64 first; the reference discards the fp32 sum of such a pair, :579-583).
  * Re-entrant per context; use one context per calling thread (the reference calls this path from up to 128 workers,
  * haplotypecaller_engine.cpp:119). */
 int phmm_compute(phmm_context *ctx, const phmm_batch *batch, float *out_raw_f32, double *out_log10, phmm_stats *stats);
