@@ -78,6 +78,7 @@ def test_smith_waterman_line_has_its_issue_roofline():
 def test_device_line_carries_the_measured_traffic():
     d = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-adapter")
     assert d["roofline"]["traffic"] and d["roofline"]["traffic"] < d["roofline"]["algorithmic_bytes"]  # reads shared 25x / 40x inside the L2s
+    assert d["kernel_build_id"] and d["kernel_build_id"] == d["counters_kernel_source_id"]  # the counters were taken on these kernels
     assert 0.5 < d["roofline_issue"]["frac"] <= 1.0
     # the other configs ride on the default line, each checked against the CPU leg on a sample
     cfg = d["configs"]

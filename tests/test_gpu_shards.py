@@ -228,7 +228,7 @@ def _long_pair(rng, R, H, sub_rate=0.01):
     return (seq, q, g, g, np.full(R, 10, np.uint8)), hap
 
 
-def test_config5_corner_10k_by_12k(engine):
+def test_config5_corner_10k_by_12k(engine, monkeypatch):
     # the corner of BASELINE config 5: the longest read against the longest haplotype (largest carry slab, largest LDS plane
     # staging, the dynamic-LDS attribute path) and a short read against it.  The reference sizes its row buffers as VLAs on
     # the stack for this (core/avx512_s.cpp:269-277); here the carry lives in HBM.
@@ -246,6 +246,10 @@ def test_config5_corner_10k_by_12k(engine):
     fin = np.isfinite(ol10)
     assert np.array_equal(l10[fin], ol10[fin])
     assert int(st.n_rescued) == int(oresc.sum())
+    # the same with the fp64 kernel first (what the library does by default once such pairs have been seen to underflow)
+    monkeypatch.setenv("PHMM_F64_FIRST", "1")
+    fraw, fl10, fst = engine.compute(b)
+    assert np.array_equal(fl10, l10, equal_nan=True) and int(fst.n_rescued) == int(st.n_rescued) and (fraw < np.float32(1e-28)).all()
 
 
 def test_config5_full_size_properties(engine, monkeypatch):
