@@ -68,9 +68,10 @@ __global__ void __launch_bounds__(systolic_block_threads<G>(), (ragged_min_waves
 // SIMD that holds one 168-register wave has room for two more waves, not three: the small-K waves, three quarters of the work, spend
 // the pass at three waves per SIMD instead of four (config 3's one-shot call, round 4: every chunk 16 % slower than the resident
 // rate, 10.1 ms of device time for 7.9 ms of sweeps; config 2, one class and one kernel per chunk, loses nothing).  Here the classes
-// whose 16-lane sweep needs more than 128 registers (reads of 193-256 bases; from 177 with per-base gap-opens) take the 32-lane shape
+// whose 16-lane sweep needs much more than 128 registers (reads of 209-256 bases; from 177 with per-base gap-opens) take the 32-lane shape
 // instead -- two pairs per wave, 6-8 rows per lane, about 100 registers -- so that ONE kernel at four waves per SIMD holds every class.
-// Those classes issue about 1.16x the instructions; everything else is the sweep it always was.  Same bits either way.
+// Those classes issue about 1.2x the instructions (eight rows carry the per-step overhead that sixteen did); everything else is the
+// sweep it always was.  Same bits either way.
 // ----------------------------------------------------------------------------------------------------
 template <typename T, int MODE, int K, int KHI>
 __device__ __forceinline__ void ragged_dispatch32(uint32_t rows, const KernelArgs &a, uint32_t wg, const RaggedSeg &sg)
@@ -86,7 +87,18 @@ __device__ __forceinline__ void ragged_dispatch32(uint32_t rows, const KernelArg
 }
 
 // the largest rows per lane the 16-lane sweep runs at four waves per SIMD, and the rows per lane of the 32-lane classes above it
-template <int MODE> constexpr int uniform_k16_max() { return MODE == 2 ? 12 : 11; }
+// (-DPHMM_UNIFORM_K16_MAX_UGO=n / _UG=n move the border: tuning hooks.)  Beyond 12 / 11 rows the 16-lane sweeps no longer fit 128
+// registers and the compiler spills: 14 dwords per lane at 13 rows with one gap-open quality, 68 at 14, 91 at 16; 68 at 12 rows with
+// per-base gap-opens.  Fourteen dwords of scratch traffic per step cost less than the 32-lane shape's 1.2x instructions -- config 3's
+// one-shot call 9.04-9.26 -> 8.81-8.84 ms with the border at 13, 9.5 at 14, 13.0 at 15, 19.2 at 16 (round 4, A/B on one box) -- so the
+// one-gap-open border is 13; the per-base one stays at 11.
+#ifndef PHMM_UNIFORM_K16_MAX_UGO
+#define PHMM_UNIFORM_K16_MAX_UGO 13
+#endif
+#ifndef PHMM_UNIFORM_K16_MAX_UG
+#define PHMM_UNIFORM_K16_MAX_UG 11
+#endif
+template <int MODE> constexpr int uniform_k16_max() { return MODE == 2 ? PHMM_UNIFORM_K16_MAX_UGO : PHMM_UNIFORM_K16_MAX_UG; }
 template <int MODE> constexpr int uniform_k32_min() { return (16 * uniform_k16_max<MODE>() + 1 + 31) / 32; }
 
 template <typename T, int MODE>
@@ -98,9 +110,12 @@ __global__ void __launch_bounds__(kBlockThreads, 4) pairhmm_systolic_ragged_unif
     for (uint32_t i = 1; i < m.n_seg; ++i)
         if (b >= m.seg[i].wg_first) s = i;
     const RaggedSeg sg = m.seg[s];
-    if (sg.lanes == 32u)
-        ragged_dispatch32<T, MODE, uniform_k32_min<MODE>(), kMaxRowsPerLaneMid>(sg.rows, a, b - sg.wg_first, sg);
-    else
+    if constexpr (uniform_k32_min<MODE>() <= kMaxRowsPerLaneMid) {
+        if (sg.lanes == 32u) {
+            ragged_dispatch32<T, MODE, uniform_k32_min<MODE>(), kMaxRowsPerLaneMid>(sg.rows, a, b - sg.wg_first, sg);
+            return;
+        }
+    }
         ragged_dispatch<T, MODE, 16, 1, uniform_k16_max<MODE>()>(sg.rows, a, b - sg.wg_first, sg);
 }
 
