@@ -39,6 +39,17 @@ def test_random_long_read_batches(engines, seed, iterations):
         fuzz_cases.pairhmm_iteration(eng, rng, it, long_bias=True, long_pair_cap=5)
 
 
+@pytest.mark.parametrize("seed,iterations", [(77, 40), (417, 30)])
+def test_random_long_read_batches_fp64_first(engines, seed, iterations, monkeypatch):
+    # the same long-read mix with the fp64 kernel first on every striped range (what the library does by default once a range has been
+    # underflowing): the fp32 kernel then runs only for the pairs that might not underflow -- random reads here, so both kinds occur
+    monkeypatch.setenv("PHMM_F64_FIRST", "1")
+    eng, _ = engines
+    rng = np.random.default_rng(seed)
+    for it in range(1, iterations + 1):
+        fuzz_cases.pairhmm_iteration(eng, rng, it, long_bias=True, long_pair_cap=5, f64_first=True)
+
+
 def test_random_regions_through_the_adapter():
     assert hostapi.init_pairhmm_ptr_gpu(0)
     rng = np.random.default_rng(1234)
