@@ -13,6 +13,8 @@
 #include <cmath>
 #include <new>
 
+#include <emmintrin.h>
+
 #include "pairhmm_engine.h"
 
 struct phmm_stage
@@ -31,6 +33,7 @@ struct phmm_stage
     uint64_t n_pairs = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool in_flight = false;
+    bool rescue_deferred = false;              // the submission's fp64 re-run is phmm_stage_wait's to launch, if a sum underflowed
     bool valid = false;                        // the last submission succeeded: the results and pair_first describe it
     phmm_stage_params params{};
 };
@@ -360,7 +363,11 @@ int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint3
         HIP_TRY(phmm::launch_stage_setup(sa, c->stream));
         rb.queue_is_empty = true;
         int r = impl::sweep_fp32(c, &rb);
-        if (r == PHMM_OK) r = impl::sweep_rescue(c, &rb);
+        // The fp64 re-run is phmm_stage_wait's business: it sees the fp32 sums in the stage's pinned memory and launches the re-run only
+        // when one of them underflowed.  Enqueued here, behind every sweep, the re-run launch -- nearly always empty -- sat on every
+        // submission's critical path (round 4; the one-shot pipeline's collector does the same).  PHMM_STAGE_EAGER_RESCUE=1: A/B hook.
+        st->rescue_deferred = r == PHMM_OK && phmm_hook("PHMM_STAGE_EAGER_RESCUE") == nullptr;
+        if (r == PHMM_OK && !st->rescue_deferred) r = impl::sweep_rescue(c, &rb);
         if (r != PHMM_OK) return r;
         HIP_TRY(hipEventRecord(st->ev1, c->stream));
         return PHMM_OK;
@@ -386,6 +393,33 @@ int phmm_stage_wait(phmm_context *c, phmm_stage *st, phmm_stats *stats)
     if (!c->cpu && st->in_flight) {
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipEventSynchronize(st->ev1));
+        if (st->rescue_deferred) {
+            st->rescue_deferred = false;
+            // (four sums per compare: the scan is on every submission's way to its workers -- 43 000 sums took 17 us one by one)
+            bool any = false;
+            uint64_t p = 0;
+            {
+                const __m128 thr = _mm_set1_ps(PHMM_MIN_ACCEPTED_F32);
+                __m128 acc0 = _mm_setzero_ps(), acc1 = _mm_setzero_ps();
+                for (; p + 8 <= st->n_pairs; p += 8) {  // (raw32 is 64-byte aligned: the stage's arena)
+                    acc0 = _mm_or_ps(acc0, _mm_cmplt_ps(_mm_loadu_ps(st->raw32 + p), thr));
+                    acc1 = _mm_or_ps(acc1, _mm_cmplt_ps(_mm_loadu_ps(st->raw32 + p + 4), thr));
+                }
+                any = _mm_movemask_ps(_mm_or_ps(acc0, acc1)) != 0;
+            }
+            for (; p < st->n_pairs && !any; ++p) any = st->raw32[p] < PHMM_MIN_ACCEPTED_F32;
+            if (any) {  // rare: the queues the fp32 kernels filled are still in the stage's device memory
+                int rc = impl::sweep_rescue(c, &st->rb);
+                if (rc == PHMM_OK && hipEventRecord(st->ev1, c->stream) != hipSuccess) rc = fail(PHMM_E_HIP, "phmm_stage_wait: hipEventRecord failed");
+                if (rc == PHMM_OK && hipEventSynchronize(st->ev1) != hipSuccess) rc = fail(PHMM_E_HIP, "phmm_stage_wait: the fp64 re-run failed");
+                if (rc != PHMM_OK) {
+                    (void)hipStreamSynchronize(c->stream);
+                    st->in_flight = false;
+                    st->valid = false;
+                    return rc;
+                }
+            }
+        }
         st->in_flight = false;
         if (stats) {
             float f = 0.f;
