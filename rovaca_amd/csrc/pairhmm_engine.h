@@ -279,7 +279,7 @@ struct phmm_resident
     float *out32_host = nullptr;
     double *out64_host = nullptr;
     bool queue_is_empty = false;     // the set-up launch has just zeroed rescue_count
-    // fp64 first (pairhmm_capi.cpp): striped ranges whose fp32 pass is skipped this pass; what the last finished pass observed per
+    // fp64 first (pairhmm_sweep.cpp): striped ranges whose fp32 pass is skipped this pass; what the last finished pass observed per
     // striped queue (pairs, of which fp64 decided), read back asynchronously into `hist_host` behind `hist_ready`
     bool queue_f64_first[phmm::kRescueQueues] = {};
     struct StripedLaunchPlan
@@ -373,10 +373,11 @@ using phmm_detail::guarded;
 // catch whatever a body may throw, so that nothing crosses the C boundary.
 namespace impl
 {
-// pairhmm_capi.cpp: one pass over a resident batch, enqueued on the context's stream set; the CPU backend's two steps
+// pairhmm_sweep.cpp: one pass over a resident batch, enqueued on the context's stream set; pairhmm_capi.cpp: the CPU backend's two steps
 int ensure_side_streams(phmm_context *c);  // the context's side streams and join events, made on first use
 int sweep_fp32(phmm_context *c, phmm_resident *rb);
 int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLane *on = nullptr);
+void harvest_history(phmm_context *c, phmm_resident *rb);  // fp64 first: fold what the batch's last finished pass observed into the history
 int cpu_upload(phmm_context *c, const phmm_batch *b, phmm_resident *rb);
 int cpu_sweep(phmm_context *c, phmm_resident *rb);
 int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, double *out_log10, phmm_stats *stats);

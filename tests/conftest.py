@@ -8,7 +8,7 @@ import pytest
 os.environ.setdefault("PHMM_ENABLE_TEST_HOOKS", "1")
 # Long pairs are swept fp32 first, as the reference does, throughout the suite -- so that the fp32 sum of EVERY pair can be compared
 # with the oracle's.  The library's default is adaptive: a range of long pairs that has been underflowing runs fp64 first and reports
-# the fp32 sums of the pairs it can prove underflowed as 0 (pairhmm_capi.cpp, "fp64 first"); the tests of that order set the hook
+# the fp32 sums of the pairs it can prove underflowed as 0 (pairhmm_sweep.cpp, "fp64 first"); the tests of that order set the hook
 # to 1 or remove it.
 os.environ.setdefault("PHMM_F64_FIRST", "0")
 

@@ -382,7 +382,7 @@ def _long_reads_around_the_fp32_threshold(seed, n_per_step=2):
 @pytest.mark.parametrize("waves", [1, 4])
 def test_fp64_first_decides_every_pair_as_fp32_first_does(engine, waves, lanes, monkeypatch):
     # A range of long pairs that has been underflowing is swept fp64 FIRST (every pair), and the fp32 kernel then runs only for the
-    # pairs whose fp64 sum says fp32 might not underflow (pairhmm_capi.cpp, "fp64 first"); PHMM_F64_FIRST=1 / 0 force the order.  Pairs
+    # pairs whose fp64 sum says fp32 might not underflow (pairhmm_sweep.cpp, "fp64 first"); PHMM_F64_FIRST=1 / 0 force the order.  Pairs
     # on both sides of the fp32 threshold and close to it: the log10 likelihoods, the set of re-run pairs and the fp32 sums of the
     # accepted pairs are bit for bit those of the fp32-first order and the oracle's; the fp32 sum of a pair that provably underflows is
     # reported as 0.
