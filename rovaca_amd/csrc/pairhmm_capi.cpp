@@ -755,6 +755,12 @@ int phmm_download(phmm_context *c, phmm_resident *rb, float *out_raw_f32, double
         }
     }
     const bool want64 = out_log10 && rb->last_rescued && n;
+    if (want64 && rb->rescue_deferred) {  // phmm_compute left the fp64 re-run to us: some pairs did underflow
+        rb->rescue_deferred = false;
+        const int rc = sweep_rescue(c, rb);
+        if (rc != PHMM_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));  // (the call's device span ends here)
+    }
     if (want64) {
         HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(rb->out_stage.p) + off64, rb->raw64.p, n * sizeof(double),
                                hipMemcpyDeviceToHost, c->stream));
@@ -879,10 +885,21 @@ int phmm_compute(phmm_context *c, const phmm_batch *b, float *out_raw_f32, doubl
     if (rc != PHMM_OK) return rc;
     // one pass; the events are read only after the download's synchronisation (no extra round trip for the timing)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    rc = impl::phmm_sweep(c, rb);
+    rc = sweep_fp32(c, rb);
     if (rc != PHMM_OK) return rc;
+    // The fp64 re-run: the download below sees how many pairs the fp32 kernels queued and launches it only if there are any -- the
+    // nearly always empty launch is off the call's critical path, as in the chunk pipeline and the stages.  (A range of long pairs
+    // that runs fp64 FIRST has both its kernels in sweep_rescue: no deferring then.)
+    bool rescue_now = out_log10 == nullptr;  // (nobody to fetch the fp64 sums for: keep the device state of a whole pass anyway)
+    for (int qi = 1; qi <= 4; ++qi) rescue_now = rescue_now || rb->queue_f64_first[qi];
+    if (rescue_now) {
+        rc = sweep_rescue(c, rb);
+        if (rc != PHMM_OK) return rc;
+    }
+    rb->rescue_deferred = !rescue_now;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     rc = impl::phmm_download(c, rb, out_raw_f32, out_log10, stats);
+    rb->rescue_deferred = false;
     if (rc == PHMM_OK && stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));

@@ -279,6 +279,7 @@ struct phmm_resident
     float *out32_host = nullptr;
     double *out64_host = nullptr;
     bool queue_is_empty = false;     // the set-up launch has just zeroed rescue_count
+    bool rescue_deferred = false;    // phmm_compute: the fp64 re-run of this pass is phmm_download's to launch, if any pair underflowed
     // fp64 first (pairhmm_sweep.cpp): striped ranges whose fp32 pass is skipped this pass; what the last finished pass observed per
     // striped queue (pairs, of which fp64 decided), read back asynchronously into `hist_host` behind `hist_ready`
     bool queue_f64_first[phmm::kRescueQueues] = {};
