@@ -296,7 +296,7 @@ public:
                 n->min_q.store(min_q, std::memory_order_relaxed);
                 n->pcr_model.store(pcr_model, std::memory_order_relaxed);
                 n->n_regions = n->n_reads = n->n_haps = 0;
-                const Cursor fresh_cur = Cursor::make(0, 0, 0, 0, 0, n->cur.generation() + 1, false);
+                const Cursor fresh_cur = Cursor::make(0, 0, 0, 0, 0, cursor_peek(&n->cur).generation() + 1, false);
                 __atomic_store_n(&n->cur.hi, fresh_cur.hi, __ATOMIC_RELAXED);
                 __atomic_store_n(&n->cur.lo, fresh_cur.lo, __ATOMIC_RELEASE);  // (no reservation can be in flight on a closed stage)
                 open_.store(n, std::memory_order_release);
