@@ -19,6 +19,7 @@ for sh in shapes:
     rb = eng.upload(b)
     for _ in range(2):
         rb.sweep()
+        eng.synchronize()  # (the order of passes for long pairs goes by what the last FINISHED pass saw)
     ms, ms32 = rb.sweep_timed(5)
     _, _, st = rb.download()
     print(f"{name:>14s}: {b.n_pairs} pairs, pass {ms:7.3f} ms = fp32 {ms32:6.3f} + fp64 {ms - ms32:6.3f} (rescued {int(st.n_rescued)})  "
