@@ -160,6 +160,7 @@ int compute_chunked(phmm_context *c, const phmm_batch *b, const std::vector<Chun
         if (!c->chunk_slot[i]) {
             c->chunk_slot[i] = new (std::nothrow) phmm_resident();
             if (!c->chunk_slot[i]) return fail(PHMM_E_NOMEM, "phmm_compute: out of host memory");
+            c->chunk_slot[i]->fp32_first_only = true;  // (the collector decides pair by pair on the fp32 sums it sees: pairhmm_sweep.cpp, "fp64 first")
         }
         if (!c->chunk_up[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_up[i], hipEventDisableTiming));
         if (!c->chunk_swept[i]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_swept[i], hipEventDisableTiming));

@@ -283,6 +283,7 @@ struct phmm_resident
     // fp64 first (pairhmm_sweep.cpp): striped ranges whose fp32 pass is skipped this pass; what the last finished pass observed per
     // striped queue (pairs, of which fp64 decided), read back asynchronously into `hist_host` behind `hist_ready`
     bool queue_f64_first[phmm::kRescueQueues] = {};
+    bool fp32_first_only = false;  // a chunk slot of the one-shot pipeline: its two passes are launched by different threads, fp32 first always
     struct StripedLaunchPlan
     {
         TeamShape sh{16, 1};

@@ -101,7 +101,7 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         for (int qi = 0; qi < kQueues; ++qi) rb->queue_f64_first[qi] = false;
         for (const Bin &bin : rb->bins) {
             const int qi = bin.queue;
-            if (!(qi >= 1 && qi <= 4) || !rb->queue_sparse[qi] || rb->out32_host) continue;
+            if (!(qi >= 1 && qi <= 4) || !rb->queue_sparse[qi] || rb->out32_host || rb->fp32_first_only) continue;
             if ((uint64_t)bin.max_read_len + bin.max_hap_len > (1u << 18)) continue;  // (the bound above is argued with room to spare up to here)
             const bool known = rb->f64_share_known[qi] || c->f64_share_known;
             const float share = rb->f64_share_known[qi] ? rb->f64_share[qi] : c->f64_share;
