@@ -39,11 +39,15 @@ def test_random_long_read_batches(engines, seed, iterations):
         fuzz_cases.pairhmm_iteration(eng, rng, it, long_bias=True, long_pair_cap=5)
 
 
-@pytest.mark.parametrize("seed,iterations", [(77, 40), (417, 30)])
-def test_random_long_read_batches_fp64_first(engines, seed, iterations, monkeypatch):
+@pytest.mark.parametrize("seed,iterations,order", [(77, 40, "1"), (417, 30, "1"), (78, 40, None)])
+def test_random_long_read_batches_fp64_first(engines, seed, iterations, order, monkeypatch):
     # the same long-read mix with the fp64 kernel first on every striped range (what the library does by default once a range has been
-    # underflowing): the fp32 kernel then runs only for the pairs that might not underflow -- random reads here, so both kinds occur
-    monkeypatch.setenv("PHMM_F64_FIRST", "1")
+    # underflowing): the fp32 kernel then runs only for the pairs that might not underflow -- random reads here, so both kinds occur.
+    # order None: no hook at all, the library's default -- each batch goes by what the engine's earlier batches saw
+    if order is None:
+        monkeypatch.delenv("PHMM_F64_FIRST", raising=False)
+    else:
+        monkeypatch.setenv("PHMM_F64_FIRST", order)
     eng, _ = engines
     rng = np.random.default_rng(seed)
     for it in range(1, iterations + 1):
