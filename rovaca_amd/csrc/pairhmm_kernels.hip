@@ -562,7 +562,15 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
     uint32_t *team_rec = reinterpret_cast<uint32_t *>(reinterpret_cast<T *>(lds + kGroups * plane_words) + static_cast<size_t>(WP) * kGroups * 3u * kRing);
     // carry rows: one slab per (team, wave), laid out [column][group][M, X, Y] so that the slab base is wave-uniform (an
     // SGPR pair) and lane 15 writes its three values with one store; stripe v reads the slab of the wave that ran v - 1
+    // The wave's ROLE in the team (which stripes it sweeps) is its hardware index rotated by the team's: a workgroup's waves go to the
+    // CU's four SIMDs in order, so without the rotation the waves that sweep stripe 0 of every pair -- the only busy ones while the
+    // fp32 pass walks its full-width first stripe -- all sat on SIMD 0 of their CUs, four to a SIMD, while SIMDs 1-3 slept (round 4:
+    // 350 cycles per 35-instruction step).  PHMM_BAND_NO_ROLE_ROTATION: A/B build hook.
+#ifdef PHMM_BAND_NO_ROLE_ROTATION
     const uint32_t uwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+#else
+    const uint32_t uwave = ((uint32_t)__builtin_amdgcn_readfirstlane((int)wave) + team) % WP;
+#endif
     const uint32_t prev_wave = (uwave + WP - 1) % WP;
     T *wbase = carry + (static_cast<size_t>(team) * WP + uwave) * 3u * kGroups * carry_stride;
     const T *rbase = carry + (static_cast<size_t>(team) * WP + prev_wave) * 3u * kGroups * carry_stride;

@@ -11,6 +11,7 @@ def funcs(path):
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", s, re.S | re.M):
         body = re.sub(r";.*", "", m.group(2))
         body = re.sub(r"\.LBB\d+_\d+", "L", body)
+        body = re.sub(r"^\s*\.amdhsa_kernarg_size.*$", "", body, flags=re.M)  # (the argument struct may grow at its end)
         out[m.group(1)] = body
     return out
 
