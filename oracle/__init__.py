@@ -24,8 +24,19 @@ f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 
+def under_profiler():
+    """rocprofv3 / rocprof preload a tool library that initialises the GPU before main(): such a process must not fork + exec."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ)
+
+
 def build():
-    """(Re)build oracle/_build and, where /root/reference exists, oracle/_ref."""
+    """(Re)build oracle/_build and, where /root/reference exists, oracle/_ref.  Refused under a profiler: `make` and the compilers
+    would be exec'd from a process whose GPU the profiler's preloaded library has initialised (forbidden on the GPU pool); build
+    beforehand (`python -c 'import __graft_entry__ as g; g.build()'`)."""
+    if under_profiler():
+        raise RuntimeError("oracle: libraries are missing and a profiler is attached -- build them first (make -C oracle), "
+                           "this process must not start child processes")
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
 
 

@@ -97,6 +97,11 @@ struct KernelArgs
     // ALL pairs of the range with rescue_list set queues -- at the pair's position, sparse_order -- every pair whose sum is at least
     // need32_above: the pairs whose fp32 sum might reach 1e-28, for which the fp32 kernel then runs and decides as the reference does
     double need32_above;
+    // table kernels (pairhmm_kernels_tab.hip): the haplotypes' bytes, and the longest haplotype of the launch (sizes the LDS of a pair)
+    const uint8_t *hap_bases;
+    const uint32_t *hap_off;
+    uint32_t tab_max_hap;
+    uint32_t tab_slots;  // tables per workgroup (LDS)
 };
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;
 constexpr int kTimelineStripes = 64, kTimelineWords = 8;
@@ -105,6 +110,16 @@ constexpr int kTimelineStripes = 64, kTimelineWords = 8;
 // uniform_gop (only with uniform_gcp): every base of the batch has the same gap-open quality too -> the variant that shares p_mm / p_mx
 hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool uniform_gcp, const KernelArgs &a, hipStream_t s,
                                bool uniform_gop = false);
+// Table kernels (pairhmm_kernels_tab.hip, pairhmm_systolic_tab.h): the same sweep with the prior looked up in an LDS table per read
+// instead of selected by a match bit.  The Rovaca case only (one gap-continuation quality, deletion == insertion gap-opens), 16 lanes
+// per pair; uniform_gop as in launch_systolic_f32.  KernelArgs::hap_bases / hap_off / tab_max_hap / tab_slots must be set;
+// tab_slots_for says how many tables fit a workgroup at the kernel's occupancy (0: the class cannot take the table kernel).
+constexpr int kTabMaxRows = 16;
+// waves per SIMD the table kernels are compiled for (register budget) and sized for (LDS): 7 K + 25 registers with one gap-open
+// quality, 8 K + 25 with per-base gap-opens
+#define PHMM_TAB_MIN_WAVES(K, UGO) (((UGO) ? (K) <= 14 : (K) <= 12) ? 4 : 3)
+uint32_t tab_slots_for(int rows_per_lane, bool uniform_gop, uint32_t max_hap);
+hipError_t launch_systolic_tab_f32(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s);
 // Ragged launches (pairhmm_kernels_ragged.hip): ONE launch over several rows-per-lane classes of a batch with mixed read lengths.
 // Every workgroup belongs to one class; the classes are listed in launch order (longest rows first).  KernelArgs::order / rescue_list /
 // rescue_count are the batch's whole arrays, n_pairs is not read.

@@ -1,0 +1,64 @@
+// pairhmm_kernels_tab.hip -- the one-K launches of the table sweep (pairhmm_systolic_tab.h): the single-pass systolic sweep with the
+// prior looked up in an LDS table per read instead of selected by a match bit, gfx950.  One launch per rows-per-lane class, 16 lanes per
+// pair, 256-thread workgroups (the four waves of a workgroup land on the four SIMDs of a CU; one-wave workgroups measured 8 % slower).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pairhmm_device.h"
+#include "pairhmm_systolic_tab.h"
+
+namespace phmm
+{
+
+template <int K, bool UGO>
+__global__ void __launch_bounds__(256, PHMM_TAB_MIN_WAVES(K, UGO)) pairhmm_systolic_tab_kernel(KernelArgs a)
+{
+    systolic_tab_sweep<K, UGO>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count);
+}
+
+template <int K, bool UGO>
+static hipError_t launch_tab_one(const KernelArgs &a, hipStream_t s)
+{
+    const uint32_t blocks = (a.n_pairs + 15u) / 16u;
+    uint32_t grid = blocks;
+    if (a.xcd_run_log2) {  // whole rounds of 8 runs (the extra workgroups find no pair)
+        const uint32_t round = 8u << a.xcd_run_log2;
+        grid = (blocks + round - 1) / round * round;
+    }
+    // (the bit-plane sweep a workgroup falls back to for haplotypes with N needs its planes' words)
+    const size_t shmem = std::max<size_t>(tab_lds_bytes(K, a.tab_slots, a.tab_max_hap), (size_t)16 * a.lds_words_per_group * sizeof(uint32_t));
+    hipLaunchKernelGGL((pairhmm_systolic_tab_kernel<K, UGO>), dim3(grid), dim3(256), shmem, s, a);
+    return hipGetLastError();
+}
+
+template <bool UGO, int K>
+static hipError_t launch_tab_k(int k, const KernelArgs &a, hipStream_t s)
+{
+    if (k == K) return launch_tab_one<K, UGO>(a, s);
+    if constexpr (K < kTabMaxRows)
+        return launch_tab_k<UGO, K + 1>(k, a, s);
+    else
+        return hipErrorInvalidValue;
+}
+
+uint32_t tab_slots_for(int rows_per_lane, bool uniform_gop, uint32_t max_hap)
+{
+    if (rows_per_lane < 1 || rows_per_lane > kTabMaxRows) return 0;
+    // the LDS of a CU (160 KiB) shared out among as many workgroups as the kernel's register budget admits waves per SIMD
+    const uint32_t waves = (uint32_t)PHMM_TAB_MIN_WAVES(rows_per_lane, uniform_gop);
+    const uint32_t budget = (160u * 1024u) / waves - 256u;
+    const uint32_t fixed = tab_lds_bytes(rows_per_lane, 0, max_hap);
+    if (fixed >= budget) return 0;
+    uint32_t slots = 16;
+    while (slots && tab_lds_bytes(rows_per_lane, slots, max_hap) > budget) --slots;
+    return slots;
+}
+
+hipError_t launch_systolic_tab_f32(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s)
+{
+    if (a.n_pairs == 0) return hipSuccess;
+    if (!a.hap_bases || !a.hap_off || a.tab_slots == 0 || a.tab_slots > 16) return hipErrorInvalidValue;
+    return uniform_gop ? launch_tab_k<true, 1>(rows_per_lane, a, s) : launch_tab_k<false, 1>(rows_per_lane, a, s);
+}
+
+}  // namespace phmm

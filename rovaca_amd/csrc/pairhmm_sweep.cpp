@@ -260,7 +260,18 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
             const int k = lanes == 64 ? wide_rows(bin) : bin.rows_per_lane;
             // big four-pairs-per-wave launches: runs of 64 workgroups (1 024 pairs, a region or so) per XCD, see KernelArgs
             if (lanes == 16 && bin.count >= xcd_min && xcd_local) a.xcd_run_log2 = 6;
-            HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream, rb->uniform_gop));
+            const char *tab = phmm_hook("PHMM_TAB");
+            const uint32_t tab_slots = tab && lanes == 16 && rb->uniform_gcp && rb->hap_bases.p && rb->hap_off.p
+                                           ? phmm::tab_slots_for(k, rb->uniform_gop, bin.max_hap_len) : 0u;
+            if (tab_slots >= 4) {
+                a.hap_bases = rb->hap_bases.p;
+                a.hap_off = rb->hap_off.p;
+                a.tab_max_hap = bin.max_hap_len;
+                a.tab_slots = tab_slots;
+                HIP_TRY(phmm::launch_systolic_tab_f32(k, rb->uniform_gop, a, stream));
+            }
+            else
+                HIP_TRY(phmm::launch_systolic_f32(k, lanes, rb->uniform_gcp, a, stream, rb->uniform_gop));
             a.xcd_run_log2 = 0;
         }
         else if (bin.max_read_len <= 64u * phmm::kMaxRowsPerLaneWide && bin.max_hap_len <= kSinglePassMaxHap &&

@@ -1,0 +1,345 @@
+// pairhmm_systolic_tab.h -- the single-pass systolic sweep with the prior looked up in LDS ("table" sweep), gfx950: the sweep of ONE
+// 256-thread workgroup (16 pairs, 16 lanes each) as a function template of the rows per lane K, for the one-K kernels of
+// pairhmm_kernels_tab.hip and the ragged kernels.
+//
+// What is computed: exactly what the bit-plane sweeps compute (pairhmm_systolic_sweep.inc / pairhmm_systolic_ugo_sweep.inc: the same
+// operations in the same order on the same operands -- rovaca/avx_512_float.cc:29-181 == core/avx512_s.cpp:259-397 with the FMA
+// contraction written out), same mapping of a pair to a 16-lane array with K rows per lane, same right-aligned rows, same two in-place
+// passes per step.
+//
+// What differs is where `prior` comes from.  The bit-plane sweeps pop one match bit per cell into VCC and select (1 - e) or e/3 with
+// it: two VALU instructions per cell of the 9 (one gap-open quality) or 10 the cell costs, in kernels bound by VALU issue.  Here the
+// two go away.  prior[i][j] depends on the read row i (its base and quality) and on the haplotype SYMBOL at column j only, so a READ
+// gets a table  prior[row][symbol]  for the four symbols A, C, G, T in LDS -- 16 bytes per row, K x 256 bytes per read -- laid out so
+// that one `ds_read_b128` returns the priors of four consecutive rows of a lane for the symbol of its column:
+//
+//      quads:   slot * Q * 1024 + q * 1024 + symbol * 256 + lane * 16       (rows 4q .. 4q+3 of `lane`)
+//      halves:  symbol * 256 + (slot & 1) * 128 + lane * 8  in block slot/2  (K mod 4 == 2: the last two rows; two tables interleave)
+//      singles: symbol * 256 + (slot & 3) * 64 + lane * 4   in block slot/4  (K mod 4 == 1: the last row; four tables interleave)
+//
+// The symbol stride is 256 bytes = the width of the LDS (64 banks x 4 bytes), so whatever symbols the 16 lanes of a service group
+// (MI355X_MICROARCH.md, LDS: `ds_read_b128` is served 16 lanes at a time, and every group holds 16 DIFFERENT lane numbers mod 16) look
+// at, lane l lands on bank group l: conflict-free by construction, also when two pairs of a wave read the same table.
+//
+// The pairs of a workgroup that have the same read share its table: the 16 pairs of a workgroup are consecutive in the processing
+// order, and the order keeps the pairs of a read together (pairhmm_binning.cpp), so a workgroup needs as many tables as it has reads --
+// two or three for regions of 9-25 haplotypes -- instead of 16.  That is what makes the table affordable: LDS for `tab_slots` tables
+// (the launch says how many fit next to the haplotypes at four waves per SIMD) instead of 16.  A workgroup with more reads than slots
+// sweeps in rounds: the pairs of the first tab_slots reads, then the next ones (correct for any order, slow only for pair lists
+// that jump between reads at every pair).
+//
+// The haplotype travels as one 16-bit entry per column (symbol * 256, ready to add) in LDS as well; a lane reads the entry of ITS
+// column each step (`ds_read_u16`), adds its table base (one or two `v_add_u32`) and issues the K / 4 table reads for the NEXT step
+// while it computes this one, so the LDS latency is covered by a whole step of arithmetic.  LDS instructions do not take VALU issue
+// slots: per step and K = 10 the wave issues 71 arithmetic + 3 DPP + 2 sums + 2-3 address instructions instead of 101.
+//
+// Haplotypes with symbols outside A, C, G, T (N matches everything, anything else nothing: pairhmm_internal.cpp:27-41) are not
+// representable in a four-symbol table.  The staging loop notices them (one `v_perm_b32` per four bases), and a workgroup that holds
+// such a pair takes the bit-plane sweep instead -- same bits, the speed of the kernels of rounds 1-4.
+#ifndef ROVACA_AMD_PAIRHMM_SYSTOLIC_TAB_H_
+#define ROVACA_AMD_PAIRHMM_SYSTOLIC_TAB_H_
+#include "pairhmm_systolic.h"
+
+namespace phmm
+{
+
+template <int K> struct TabShape
+{
+    static constexpr int rem = K % 4;
+    static constexpr int quads = rem == 3 ? (K + 3) / 4 : K / 4;  // three odd rows: a padded quad
+    static constexpr int tail = rem == 3 ? 0 : rem;               // rows behind the quads: 0, 1 (b32) or 2 (b64)
+};
+
+// entries of the haplotype array of one pair: 16 in front (the columns a lane "sees" before its first step), then whole rounds of 64
+// (16 lanes x 4 bases) that cover the haplotype, its offset in its first dword, and the 15 + 2 + 1 columns the sweep looks past its end
+__host__ __device__ inline uint32_t tab_hap_rounds(uint32_t max_hap) { return (max_hap + 21u + 63u) / 64u; }
+__host__ __device__ inline uint32_t tab_hap_bytes(uint32_t max_hap) { return 2u * (16u + 64u * tab_hap_rounds(max_hap)); }
+// LDS of a workgroup: `slots` tables of K rows, the 16 pairs' haplotype entries, the 16 read ids
+__host__ __device__ inline uint32_t tab_table_region_bytes(int K, uint32_t slots)
+{
+    const int rem = K % 4, quads = rem == 3 ? (K + 3) / 4 : K / 4, tail = rem == 3 ? 0 : rem;
+    return slots * quads * 1024u + (tail == 2 ? (slots + 1) / 2 * 1024u : tail == 1 ? (slots + 3) / 4 * 1024u : 0u);
+}
+__host__ __device__ inline uint32_t tab_lds_bytes(int K, uint32_t slots, uint32_t max_hap)
+{
+    return tab_table_region_bytes(K, slots) + 16u * tab_hap_bytes(max_hap) + 64u;
+}
+
+// UGO: one gap-open quality in the batch (pairhmm_systolic_ugo_sweep.inc); otherwise per-base gap-opens with deletion == insertion and
+// one gap-continuation quality (pairhmm_systolic_sweep.inc with UG = true: the Rovaca case with a PCR indel model).
+template <int K, bool UGO>
+__device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t wg, uint32_t pos_first, uint32_t count, uint32_t *rescue_list,
+                                                   uint32_t *rescue_count)
+{
+    using T = float;
+    constexpr int G = 16;
+    constexpr int Q = TabShape<K>::quads, TAIL = TabShape<K>::tail;
+    extern __shared__ __attribute__((aligned(256))) uint8_t lds_raw[];
+    const uint32_t lane = threadIdx.x & 15u;
+    const uint32_t grp = threadIdx.x >> 4;
+    const uint32_t gidx = wg * 16u + grp;
+    const bool valid = gidx < count;
+    const uint32_t pair = a.order[valid ? pos_first + gidx : 0];
+    const uint32_t r = a.pair_read[pair], h = a.pair_hap[pair];
+    const uint32_t R = a.read_len[r], H = a.hap_len[h];
+    const uint32_t roff = a.read_off[r];
+    const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
+    const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
+
+    // ---- LDS of the workgroup: the tables' quads, their tails (interleaved), the 16 pairs' haplotype entries, the 16 read ids ----
+    const uint32_t n_slots = a.tab_slots;
+    const uint32_t tail_at = n_slots * (Q * 1024u);
+    const uint32_t hap_at = tab_table_region_bytes(K, n_slots);
+    const uint32_t hap_stride = tab_hap_bytes(a.tab_max_hap);
+    uint8_t *hapl = lds_raw + hap_at + grp * hap_stride;
+    uint32_t *rid = reinterpret_cast<uint32_t *>(lds_raw + hap_at + 16u * hap_stride);
+
+    // ---- the haplotype: 16-bit entries (symbol * 256), entry 16 + d + (j - 1) for column j, d = the haplotype's offset in its dword.
+    // 16 lanes x one aligned dword per round; dwords that do not touch the haplotype are not read (symbol 0).  A base outside
+    // A, C, G, T makes the pair `dirty` (bases of the neighbours in the first and last dword count too: a false alarm costs speed only). ----
+    const uint32_t hoff = a.hap_off[h];
+    const uint32_t d = hoff & 3u;
+    bool dirty = false;
+    {
+        const uint8_t *src = a.hap_bases + (hoff - d);
+        if (lane < 8) reinterpret_cast<uint32_t *>(hapl)[lane] = 0;  // the 16 entries in front
+        const uint32_t rounds = tab_hap_rounds(a.tab_max_hap);
+        for (uint32_t it = 0; it < rounds; ++it) {
+            const uint32_t i = it * 16u + lane;  // dword of the haplotype's span
+            uint32_t w = 0x41414141u;
+            if (4u * i + 3u >= d && 4u * i < d + H) w = *reinterpret_cast<const uint32_t *>(src + 4u * i);
+            const uint32_t x = (w >> 1) & 0x03030303u;  // A 0, C 1, T 2, G 3 in every byte (ASCII bits 1-2)
+            dirty = dirty || __builtin_amdgcn_perm(0u, 0x47544341u, x) != w;  // the four codes back to "ACTG": any other byte differs
+            uint2 e;
+            e.x = ((x & 0xFFu) << 8) | ((x & 0xFF00u) << 16);
+            e.y = (((x >> 16) & 0xFFu) << 8) | (((x >> 16) & 0xFF00u) << 16);
+            *reinterpret_cast<uint2 *>(hapl + 2u * (16u + 4u * i)) = e;
+        }
+    }
+    if (lane == 0) rid[grp] = valid ? r : 0xFFFFFFFFu;
+    if (__syncthreads_or(valid && dirty)) {
+        // a haplotype with N (or anything else) in this workgroup: the bit-plane sweep, whose planes know those symbols
+        if constexpr (UGO)
+            systolic_ugo_sweep<T, K, 16, 256>(a, wg, pos_first, count, rescue_list, rescue_count);
+        else
+            systolic_sweep<T, K, true, 16, 256>(a, wg, pos_first, count, rescue_list, rescue_count);
+        return;
+    }
+    // ---- which table a pair uses: one per run of equal reads among the workgroup's pairs ----
+    uint32_t slot = 0, n_tables = 1;
+    bool leader = grp == 0;
+    {
+        uint32_t prev = rid[0];
+#pragma unroll
+        for (uint32_t g = 1; g < 16; ++g) {
+            const uint32_t cur = rid[g];
+            const bool chg = cur != 0xFFFFFFFFu && cur != prev;
+            n_tables += chg;
+            slot += chg && g <= grp;
+            leader = leader || (chg && g == grp);
+            prev = cur;
+        }
+    }
+
+    // ---- constants ----
+    const T init_y = Num<T>::init_const() / static_cast<T>(H);  // rovaca/avx_512_float.cc:32
+    const int pad = G * K - static_cast<int>(R);                  // rows [0, pad) are boundary replicas
+    const uint32_t c0 = a.read_gcp[roff] & 127u;
+    const T p_gapm = static_cast<T>(1.0) - ph2pr[c0];
+    const T p_xx = ph2pr[c0];
+    T u_mm = 0, u_mx = 0;  // UGO: the two factors every row shares
+    if constexpr (UGO) {
+        const uint32_t g0 = a.read_ins[roff] & 127u;
+        u_mm = mmtab[((g0 * (g0 + 1)) >> 1) + g0];  // core/context.h:162-173 with ins == del
+        u_mx = ph2pr[g0];                            // == p_my
+    }
+    T p_yy[K];
+    T r_mm[UGO ? 1 : K], r_mx[UGO ? 1 : K];  // per-base gap-opens: per row
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int row = static_cast<int>(lane) * K + k - pad;
+        p_yy[k] = row >= 0 ? p_xx : static_cast<T>(1);  // a boundary replica holds Y with p_yy = 1
+        if constexpr (!UGO) {
+            r_mm[k] = 0, r_mx[k] = 0;
+            if (row >= 0) {
+                const uint32_t g = a.read_ins[roff + static_cast<uint32_t>(row)] & 127u;
+                r_mm[k] = mmtab[((g * (g + 1)) >> 1) + g];
+                r_mx[k] = ph2pr[g];
+            }
+        }
+    }
+    auto f_mm = [&](int k) -> T { return UGO ? u_mm : r_mm[UGO ? 0 : k]; };
+    auto f_mx = [&](int k) -> T { return UGO ? u_mx : r_mx[UGO ? 0 : k]; };
+
+    const T y_col0 = (static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
+    // the entry of this lane's column at step t is hp[t]: entry 16 + d + (t - lane) - 1
+    const uint16_t *hp = reinterpret_cast<const uint16_t *>(hapl) + (15u + d - lane);
+
+#pragma unroll 1
+    for (uint32_t base = 0; base < n_tables; base += n_slots) {
+        const bool act = valid && slot >= base && slot - base < n_slots;
+        const uint32_t sl = act ? slot - base : 0u;
+        uint8_t *quads = lds_raw + sl * (Q * 1024u) + lane * 16u;
+        uint8_t *tails = lds_raw + tail_at + (TAIL == 2 ? (sl >> 1) * 1024u + (sl & 1u) * 128u + lane * 8u : (sl >> 2) * 1024u + (sl & 3u) * 64u + lane * 4u);
+        if (base) __syncthreads();  // the round before has read its tables
+        if (act && leader) {
+            // the read's table: symbol code s (ASCII bits 1-2: A 0, C 1, T 2, G 3) -> read class (A 0, C 1, G 2, T 3); a read N matches all
+            T hi[K], lo[K];
+            uint32_t cls[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int row = static_cast<int>(lane) * K + k - pad;
+                cls[k] = 5, hi[k] = 0, lo[k] = 0;  // boundary replica: prior 0 kills M
+                if (row >= 0) {
+                    const uint32_t at = roff + static_cast<uint32_t>(row);
+                    const T dist = ph2pr[a.read_qual[at] & 127u];
+                    hi[k] = static_cast<T>(1.0) - dist;
+                    lo[k] = Num<T>::div3(dist);
+                    cls[k] = read_class(a.read_bases[at]);
+                }
+            }
+            auto sel = [&](int k, uint32_t s) -> T {
+                if (k >= K) return 0;
+                const uint32_t c = s == 2u ? 3u : s == 3u ? 2u : s;
+                return (cls[k] == c || cls[k] == 4u) ? hi[k] : lo[k];
+            };
+#pragma unroll
+            for (uint32_t s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    float4 v;
+                    v.x = sel(4 * q, s), v.y = sel(4 * q + 1, s), v.z = sel(4 * q + 2, s), v.w = sel(4 * q + 3, s);
+                    *reinterpret_cast<float4 *>(quads + q * 1024 + s * 256u) = v;
+                }
+                if constexpr (TAIL == 2) {
+                    float2 v;
+                    v.x = sel(4 * Q, s), v.y = sel(4 * Q + 1, s);
+                    *reinterpret_cast<float2 *>(tails + s * 256u) = v;
+                }
+                if constexpr (TAIL == 1) *reinterpret_cast<float *>(tails + s * 256u) = sel(4 * Q, s);
+            }
+        }
+        __syncthreads();  // tables (and, the first time, the haplotype entries) are read by other lanes than wrote them
+
+        // ---- the sweep ----
+        const uint32_t Tg = act ? H + (G - 1) : 0;  // last step of this group
+        uint32_t Tmax = Tg;
+        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
+        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
+        Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
+        uint32_t Tmin = Tg;
+        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
+        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
+        Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
+        if (Tmax == 0) continue;  // none of the wave's four pairs is in this round
+
+        T M[K], X[K], Y[K];
+        T PM[UGO && K > 1 ? K - 1 : 1];  // UGO: M[k] * p_mx of the anti-diagonal before, computed in pass 2 and used again in pass 1
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            M[k] = 0;
+            X[k] = 0;
+            Y[k] = static_cast<int>(lane) * K + k < pad ? init_y : static_cast<T>(0);
+        }
+        if constexpr (UGO) {
+#pragma unroll
+            for (int k = 0; k + 1 < K; ++k) PM[k] = 0;
+        }
+        T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
+        T sumM = 0, sumX = 0;
+        T prA[K], prB[K];  // priors of this step / of the next one (the roles swap every step, like the two row-above sets)
+        auto fetch = [&](T(&pr)[K], uint32_t so) {
+            const uint8_t *tq = quads + so;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(tq + q * 1024);
+                pr[4 * q] = v.x;
+                if (4 * q + 1 < K) pr[4 * q + 1] = v.y;
+                if (4 * q + 2 < K) pr[4 * q + 2] = v.z;
+                if (4 * q + 3 < K) pr[4 * q + 3] = v.w;
+            }
+            if constexpr (TAIL == 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(tails + so);
+                pr[4 * Q] = v.x;
+                pr[4 * Q + 1] = v.y;
+            }
+            if constexpr (TAIL == 1) pr[4 * Q] = *reinterpret_cast<const float *>(tails + so);
+        };
+        // one anti-diagonal with the priors `pr`.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it
+        // at this column.  The arithmetic is the bit-plane sweeps', statement for statement.
+        auto compute = [&](T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0, const T(&pr)[K]) {
+            uM0 = dpp_shr1<G>(uM0, M[K - 1]);
+            uX0 = dpp_shr1<G>(uX0, X[K - 1]);
+            uY0 = dpp_shr1<G>(uY0, Y[K - 1]);
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                if constexpr (UGO)
+                    Y[k] = Num<T>::fma_(Y[k], p_yy[k], k == K - 1 ? M[K - 1] * u_mx : PM[k < K - 1 ? k : 0]);
+                else
+                    Y[k] = Num<T>::fma_(Y[k], p_yy[k], M[k] * f_mx(k));
+                const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
+                T tt = gM * f_mm(k);
+                tt = Num<T>::fma_(gX, p_gapm, tt);
+                tt = Num<T>::fma_(gY, p_gapm, tt);
+                M[k] = tt * pr[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            T uM = uM0, uX = uX0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const T prod = uM * f_mx(k);
+                X[k] = Num<T>::fma_(uX, p_xx, prod);
+                if constexpr (UGO)
+                    if (k >= 1) PM[k - 1] = prod;
+                uM = M[k];
+                uX = X[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
+            sumX = sumX + X[K - 1];
+        };
+        // step t: issue the table reads of step t + 1 and the haplotype read of step t + 2, then compute with what the step before fetched
+        uint32_t so_next;  // the entry of step t + 1
+        auto step = [&](uint32_t t, bool odd, bool live) {
+            if (odd) {
+                fetch(prB, so_next);
+                so_next = hp[t + 2];
+                __builtin_amdgcn_sched_barrier(0);
+                if (live) compute(aM, aX, aY, bM, bX, bY, prA);
+            }
+            else {
+                fetch(prA, so_next);
+                so_next = hp[t + 2];
+                __builtin_amdgcn_sched_barrier(0);
+                if (live) compute(bM, bX, bY, aM, aX, aY, prB);
+            }
+        };
+        // Steps go in (odd, even) couples everywhere so that the two register sets and the two prior sets swap roles without a move:
+        // the fill (steps 1..16, lane l starts at step l + 1), the steady state (every lane of all four pairs has work, no predicate)
+        // and the drain (pairs with a shorter haplotype than the wave's longest drop out; may run one dead step past Tmax).
+        uint32_t t = 1;
+        fetch(prA, hp[1]);
+        so_next = hp[2];
+        for (; t <= (uint32_t)G; t += 2) {
+            step(t, true, (t > lane) && (t <= Tg));
+            step(t + 1, false, (t + 1 > lane) && (t + 1 <= Tg));
+        }
+        for (; t + 1 <= Tmin; t += 2) {
+            step(t, true, true);
+            step(t + 1, false, true);
+        }
+        for (; t <= Tmax; t += 2) {
+            step(t, true, t <= Tg);
+            step(t + 1, false, t + 1 <= Tg);
+        }
+        if (act && lane == G - 1) {
+            const T res = sumM + sumX;
+            reinterpret_cast<T *>(a.out_raw)[pair] = res;
+            if (rescue_list && res < static_cast<T>(1e-28f))  // pairhmm_internal.cpp:578: queue for fp64
+                rescue_list[atomicAdd(rescue_count, 1u)] = pair;
+        }
+    }
+}
+
+}  // namespace phmm
+#endif
