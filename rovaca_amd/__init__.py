@@ -31,7 +31,8 @@ def kernel_source_id():
     into the library as phmm_kernel_build_id().  profiles/hbm_traffic.json records it when the PMC counters are collected
     (tools/summarize_profiles.py); bench.py and the tests refuse counters taken from other sources, other flags or another build."""
     return _source_id(("pairhmm_kernels.hip", "pairhmm_systolic.h", "pairhmm_systolic_sweep.inc", "pairhmm_systolic_ugo_sweep.inc",
-                       "pairhmm_kernels_ragged.hip", "pairhmm_device.h"))
+                       "pairhmm_kernels_ragged.hip", "pairhmm_kernels_tab.hip", "pairhmm_kernels_ragged_tab.hip", "pairhmm_systolic_tab.h",
+                       "pairhmm_device.h"))
 
 
 def sw_kernel_source_id():

@@ -98,6 +98,27 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
     }
     uint64_t cells = 0;
     const uint64_t table = (uint64_t)n_used * hrange;
+    // the length key of a pair: the longest haplotype its read is paired with (pairhmm_binning.h).  A cross product pairs every read with
+    // every haplotype; a pair list takes one pass (bad indices are reported by the counting pass below).
+    std::vector<uint32_t> &read_hmax = scratch.read_hmax;
+    if (!cross) {
+        read_hmax.assign(b->n_reads, 0);
+        const unsigned T0 = (n_pairs >= (phmm_detail::t_pool ? (1u << 15) : kParallelMinPairs) && !phmm_detail::t_serial) ? host_threads() : 1u;
+        auto max_range = [&](uint64_t lo, uint64_t hi, unsigned) {
+            for (uint64_t p = lo; p < hi; ++p) {
+                const uint32_t r = b->pair_read[p] - read_bias, h = b->pair_hap[p] - hap_bias;
+                if (r >= b->n_reads || h >= b->n_haps) continue;
+                const uint32_t H = b->hap_len[h];
+                uint32_t cur = __atomic_load_n(&read_hmax[r], __ATOMIC_RELAXED);
+                while (cur < H && !__atomic_compare_exchange_n(&read_hmax[r], &cur, H, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+            }
+        };
+        if (T0 > 1)
+            parallel_ranges(n_pairs, T0, max_range);
+        else
+            max_range(0, n_pairs, 0);
+    }
+    auto key_len = [&](uint32_t r) { return cross ? max_hap : read_hmax[r]; };
     const bool bin_trace = n_pairs >= 4096 && getenv("PHMM_PHASE_TIMING") != nullptr;  // tuning aid: where the binning's time goes, on stderr
     auto t_prev = std::chrono::steady_clock::now();
     double lap_us[6] = {0};
@@ -142,7 +163,7 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
                 const uint32_t R = b->read_len[r], H = b->hap_len[h];
                 const uint32_t k = class_of(R, H);
                 rmax_t[k] = std::max(rmax_t[k], R);
-                const uint32_t at = rank[k] * hrange + (max_hap - H);
+                const uint32_t at = rank[k] * hrange + (max_hap - key_len(r));
                 pr[p] = r;
                 ph[p] = h;
                 slot[p] = at;
@@ -235,7 +256,7 @@ int bin_pairs(const phmm_batch *b, bool cross, uint64_t n_pairs, uint32_t read_b
             ph[p] = h;
             const uint32_t R = b->read_len[r], H = b->hap_len[h];
             cells += (uint64_t)R * H;
-            keys[p] = ((uint64_t)class_of(R, H) << 56) | ((uint64_t)(0xFFFFFu - H) << 32) | p;  // H < 2^20
+            keys[p] = ((uint64_t)class_of(R, H) << 56) | ((uint64_t)(0xFFFFFu - key_len(r)) << 32) | p;  // H < 2^20
         }
         std::sort(keys.begin(), keys.end());
         for (uint64_t i = 0; i < n_pairs; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);

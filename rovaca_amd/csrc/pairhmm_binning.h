@@ -300,10 +300,13 @@ namespace phmm_detail
 {
 struct BinScratch  // host scratch of the pair binning, kept between calls by its owner
 {
-    std::vector<uint32_t> hist, slot;
+    std::vector<uint32_t> hist, slot, read_hmax;
 };
-// Pair-list form.  Order = (class, haplotype length descending, pair index), as a counting sort over (class, length) -- a
-// comparison sort was the largest host cost of a region-sized call -- or a comparison sort when the lengths are sparse.
+// Pair-list form.  Order = (class, longest haplotype OF THE PAIR'S READ descending, pair index), as a counting sort over (class,
+// length) -- a comparison sort was the largest host cost of a region-sized call -- or a comparison sort when the lengths are sparse.
+// The length key is the read's, not the pair's (round 5): the pairs of one read stay next to each other whatever the lengths of its
+// haplotypes, because the table kernels share a read's prior table among the pairs of a workgroup (pairhmm_systolic_tab.h); the
+// haplotypes of one read are those of one region, of nearly one length, so the four pairs of a wave still finish together.
 // cross: the pair list is the full cross product in (read, hap) order and pair_read / pair_hap are not read.  read_bias /
 // hap_bias are subtracted from the indices of a pair list that counts from the start of the caller's tables while b's tables
 // are windows of them.  Writes pr[p], ph[p] (the pair list as the kernels index it) and order[0 .. n_pairs), appends the

@@ -115,10 +115,13 @@ hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool unifo
 // per pair; uniform_gop as in launch_systolic_f32.  KernelArgs::hap_bases / hap_off / tab_max_hap / tab_slots must be set;
 // tab_slots_for says how many tables fit a workgroup at the kernel's occupancy (0: the class cannot take the table kernel).
 constexpr int kTabMaxRows = 16;
-// waves per SIMD the table kernels are compiled for (register budget) and sized for (LDS): 7 K + 25 registers with one gap-open
-// quality, 8 K + 25 with per-base gap-opens
-#define PHMM_TAB_MIN_WAVES(K, UGO) (((UGO) ? (K) <= 14 : (K) <= 12) ? 4 : 3)
-uint32_t tab_slots_for(int rows_per_lane, bool uniform_gop, uint32_t max_hap);
+// (registers: 7 K + 25 with one gap-open quality, 8 K + 25 with per-base gap-opens)
+// 16-lane classes up to this many rows per lane run the table sweep at four waves per SIMD (<= 128 registers); above, three
+constexpr int tab_rows_at_four_waves(bool uniform_gop) { return uniform_gop ? 14 : 12; }
+// LDS a workgroup of a table kernel may use at `waves` per SIMD, and how many tables then fit next to the 16 haplotypes (0: none)
+uint32_t tab_lds_budget(int waves);
+uint32_t tab_slots_for(int rows_per_lane, uint32_t max_hap, uint32_t lds_budget);
+constexpr uint32_t kTabMinSlots = 4;  // fewer tables than this per workgroup: the class takes the bit-plane kernel
 hipError_t launch_systolic_tab_f32(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s);
 // Ragged launches (pairhmm_kernels_ragged.hip): ONE launch over several rows-per-lane classes of a batch with mixed read lengths.
 // Every workgroup belongs to one class; the classes are listed in launch order (longest rows first).  KernelArgs::order / rescue_list /
@@ -133,12 +136,19 @@ struct RaggedSeg
     uint32_t queue;      // its rescue queue (index into rescue_count) ...
     uint32_t list_base;  // ... and where that queue's list begins in rescue_list
     uint32_t lanes;      // lanes per pair of the class's sweep (the uniform-budget kernel: 16 or 32; the K-range kernels: not read)
+    uint32_t tab_slots;  // table kernels: prior tables a workgroup of this class holds in LDS
 };
 struct RaggedArgs
 {
     uint32_t n_seg, n_wg;  // classes, workgroups in all
     RaggedSeg seg[kRaggedMaxSegs];
 };
+// Ragged launches of the table sweep (pairhmm_kernels_ragged_tab.hip), as launch_systolic_ragged_f32 / _uniform_f32 below: several
+// rows-per-lane classes in one launch.  range 0: classes up to tab_rows_at_four_waves (one kernel at four waves per SIMD), 1: the
+// classes above (three waves).  The uniform-budget form holds range 0 as table sweeps and the classes above as 32-lane bit-plane
+// sweeps (RaggedSeg::lanes), all at four waves.  RaggedSeg::tab_slots per 16-lane class; KernelArgs::tab_max_hap for the launch.
+hipError_t launch_systolic_ragged_tab_f32(bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
+hipError_t launch_systolic_ragged_tab_uniform_f32(bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
 // which ragged kernel a class belongs to (classes of one range share a kernel: the same occupancy target); -1: none
 int ragged_range_of(int rows_per_lane, int lanes_per_pair, bool uniform_gop);
 // uniform gap-continuation penalty and deletion == insertion gap-opens are required (the Rovaca case); uniform_gop as in launch_systolic_f32
@@ -219,6 +229,7 @@ struct StageSetupArgs
     int32_t min_q, pcr_model;
     uint8_t gap_open, gap_cont;
     uint32_t *rescue_count;  // kRescueQueues counters, zeroed
+    uint32_t *hap_off;       // each haplotype's offset in the arena (table kernels)
 };
 hipError_t launch_stage_setup(const StageSetupArgs &a, hipStream_t s);
 // allele marginalisation (pairhmm_marginal.hip): device pointers; old [n_old][stride], out [n_new][evidence_count]

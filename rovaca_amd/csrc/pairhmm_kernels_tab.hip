@@ -11,9 +11,9 @@ namespace phmm
 {
 
 template <int K, bool UGO>
-__global__ void __launch_bounds__(256, PHMM_TAB_MIN_WAVES(K, UGO)) pairhmm_systolic_tab_kernel(KernelArgs a)
+__global__ void __launch_bounds__(256, (K <= tab_rows_at_four_waves(UGO) ? 4 : 3)) pairhmm_systolic_tab_kernel(KernelArgs a)
 {
-    systolic_tab_sweep<K, UGO>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count);
+    systolic_tab_sweep<K, UGO>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count, a.tab_slots);
 }
 
 template <int K, bool UGO>
@@ -41,16 +41,18 @@ static hipError_t launch_tab_k(int k, const KernelArgs &a, hipStream_t s)
         return hipErrorInvalidValue;
 }
 
-uint32_t tab_slots_for(int rows_per_lane, bool uniform_gop, uint32_t max_hap)
+uint32_t tab_lds_budget(int waves)
+{
+    // the LDS of a CU (160 KiB) shared out among as many 256-thread workgroups as the register budget admits waves per SIMD
+    return (160u * 1024u) / (uint32_t)(waves < 1 ? 1 : waves) - 256u;
+}
+
+uint32_t tab_slots_for(int rows_per_lane, uint32_t max_hap, uint32_t lds_budget)
 {
     if (rows_per_lane < 1 || rows_per_lane > kTabMaxRows) return 0;
-    // the LDS of a CU (160 KiB) shared out among as many workgroups as the kernel's register budget admits waves per SIMD
-    const uint32_t waves = (uint32_t)PHMM_TAB_MIN_WAVES(rows_per_lane, uniform_gop);
-    const uint32_t budget = (160u * 1024u) / waves - 256u;
-    const uint32_t fixed = tab_lds_bytes(rows_per_lane, 0, max_hap);
-    if (fixed >= budget) return 0;
+    if (tab_lds_bytes(rows_per_lane, 0, max_hap) >= lds_budget) return 0;
     uint32_t slots = 16;
-    while (slots && tab_lds_bytes(rows_per_lane, slots, max_hap) > budget) --slots;
+    while (slots && tab_lds_bytes(rows_per_lane, slots, max_hap) > lds_budget) --slots;
     return slots;
 }
 
@@ -59,6 +61,20 @@ hipError_t launch_systolic_tab_f32(int rows_per_lane, bool uniform_gop, const Ke
     if (a.n_pairs == 0) return hipSuccess;
     if (!a.hap_bases || !a.hap_off || a.tab_slots == 0 || a.tab_slots > 16) return hipErrorInvalidValue;
     return uniform_gop ? launch_tab_k<true, 1>(rows_per_lane, a, s) : launch_tab_k<false, 1>(rows_per_lane, a, s);
+}
+
+// the ragged forms live in pairhmm_kernels_ragged_tab.hip, compiled once per arithmetic form
+hipError_t launch_systolic_ragged_tab_ugo_f32(const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
+hipError_t launch_systolic_ragged_tab_ug_f32(const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
+hipError_t launch_systolic_ragged_tab_uniform_ugo_f32(const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
+hipError_t launch_systolic_ragged_tab_uniform_ug_f32(const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
+hipError_t launch_systolic_ragged_tab_f32(bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s)
+{
+    return uniform_gop ? launch_systolic_ragged_tab_ugo_f32(a, m, s) : launch_systolic_ragged_tab_ug_f32(a, m, s);
+}
+hipError_t launch_systolic_ragged_tab_uniform_f32(bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s)
+{
+    return uniform_gop ? launch_systolic_ragged_tab_uniform_ugo_f32(a, m, s) : launch_systolic_ragged_tab_uniform_ug_f32(a, m, s);
 }
 
 }  // namespace phmm

@@ -290,6 +290,7 @@ __global__ void __launch_bounds__(kStageSetupThreads) stage_setup_kernel(StageSe
     if (threadIdx.x == 0) {
         s.hap_len[h] = H;
         s.plane_off[h] = d.plane_off;
+        s.hap_off[h] = d.off;  // the table kernels read the haplotype's bases (in the arena) themselves
     }
     // One column per lane, one ballot per plane: a wave turns 64 columns into two words of each plane with no loop at all.  (The
     // first form of this kernel gave every word to one thread that walked its 32 columns -- 32 dependent steps on a chip that

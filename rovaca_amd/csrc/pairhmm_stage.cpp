@@ -137,7 +137,7 @@ int phmm_stage_create(phmm_context *c, const phmm_stage_caps *caps, phmm_stage *
     const size_t d_arena = dreserve(st->arena_cap);
     const size_t d_qual = dreserve(k.max_bytes), d_gop = dreserve(k.max_bytes), d_gcp = dreserve(k.max_bytes);
     const size_t d_roff = dreserve((size_t)k.max_reads * 4), d_rlen = dreserve((size_t)k.max_reads * 4);
-    const size_t d_hlen = dreserve((size_t)k.max_haps * 4), d_poff = dreserve((size_t)k.max_haps * 4);
+    const size_t d_hlen = dreserve((size_t)k.max_haps * 4), d_poff = dreserve((size_t)k.max_haps * 4), d_hoff = dreserve((size_t)k.max_haps * 4);
     const size_t d_pr = dreserve((size_t)k.max_pairs * 4), d_ph = dreserve((size_t)k.max_pairs * 4), d_order = dreserve((size_t)k.max_pairs * 4);
     hipError_t e = rb.blob.alloc(dtotal);
     if (e == hipSuccess) e = rb.planes.alloc(plane_words_cap(k));
@@ -162,6 +162,8 @@ int phmm_stage_create(phmm_context *c, const phmm_stage_caps *caps, phmm_stage *
     rb.read_len = {reinterpret_cast<uint32_t *>(d + d_rlen), k.max_reads};
     rb.hap_len = {reinterpret_cast<uint32_t *>(d + d_hlen), k.max_haps};
     rb.plane_off = {reinterpret_cast<uint32_t *>(d + d_poff), k.max_haps};
+    rb.hap_off = {reinterpret_cast<uint32_t *>(d + d_hoff), k.max_haps};  // written by the set-up launch: offsets in the arena
+    rb.hap_bases = {d + d_arena, k.max_bytes};                             // (the haplotypes' bases lie in the arena)
     rb.pair_read = {reinterpret_cast<uint32_t *>(d + d_pr), k.max_pairs};
     rb.pair_hap = {reinterpret_cast<uint32_t *>(d + d_ph), k.max_pairs};
     rb.order = {reinterpret_cast<uint32_t *>(d + d_order), k.max_pairs};
@@ -344,6 +346,7 @@ int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint3
     sa.read_len = rb.read_len.p;
     sa.hap_len = rb.hap_len.p;
     sa.plane_off = rb.plane_off.p;
+    sa.hap_off = rb.hap_off.p;
     sa.planes = rb.planes.p;
     sa.pair_read = rb.pair_read.p;
     sa.pair_hap = rb.pair_hap.p;

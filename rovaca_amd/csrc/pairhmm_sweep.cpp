@@ -122,6 +122,18 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
     {
         size_t first, n;  // bins [first, first + n)
         int lanes;        // single-pass launches: lanes per pair (16 / 64); 0: not decided here (striped, or the per-bin rule); -1: uniform-budget ragged kernel (16 or 32 per class)
+        bool tab;         // ragged launches: the table sweep (pairhmm_systolic_tab.h) instead of the bit-plane one
+    };
+    // The table sweep (round 5): the Rovaca case (one gap-continuation quality, deletion == insertion gap-opens), 16 lanes per pair,
+    // the haplotypes' bases on the device, and LDS for at least kTabMinSlots prior tables per workgroup next to its 16 haplotypes
+    // (haplotypes of a thousand bases and more leave no room: bit-plane kernels).  PHMM_NO_TAB: A/B and test hook.
+    const bool tab_on = rb->uniform_gcp && rb->hap_bases.p && rb->hap_off.p && !phmm_hook("PHMM_NO_TAB");
+    auto tab_slots_of = [&](int k16, uint32_t max_hap) -> uint32_t {
+        if (!tab_on || k16 < 1 || k16 > phmm::kTabMaxRows) return 0u;
+        const uint32_t n = phmm::tab_slots_for(k16, max_hap, phmm::tab_lds_budget(k16 <= phmm::tab_rows_at_four_waves(rb->uniform_gop) ? 4 : 3));
+        if (const char *f = phmm_hook("PHMM_TAB_SLOTS"))  // tests: few tables per workgroup, so that workgroups sweep in rounds
+            return n ? std::min<uint32_t>(n, (uint32_t)std::max(1, atoi(f))) : 0u;
+        return n >= phmm::kTabMinSlots ? n : 0u;
     };
     uint32_t wide_max = kWideMaxPairs;
     if (const char *f = phmm_hook("PHMM_WIDE_MAX_PAIRS")) wide_max = (uint32_t)std::max(0, atoi(f));  // tuning
@@ -141,7 +153,7 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
             continue;
         }
         if (!(rb->ragged && rb->bins[i].rows_per_lane > 0)) {
-            launches.push_back(FpLaunch{i, 1, 0});
+            launches.push_back(FpLaunch{i, 1, 0, false});
             ++i;
             continue;
         }
@@ -156,18 +168,31 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         // the K-range kernels below are better: their mix is over after the first third of the pass.
         uint64_t uniform_below = kRaggedUniformBelowPairs;
         if (const char *f = phmm_hook("PHMM_RAGGED_UNIFORM_BELOW")) uniform_below = (uint64_t)std::max(0ll, atoll(f));  // tests, tuning
+        // the run as table sweeps: every class that would run 16 lanes per pair must have room for its tables (the LDS of a launch is
+        // sized by the run's longest haplotype)
+        uint32_t run_max_hap = 0;
+        for (size_t q = i; q < j; ++q) run_max_hap = std::max(run_max_hap, rb->bins[q].max_hap_len);
+        const int k4 = phmm::tab_rows_at_four_waves(rb->uniform_gop);
         if (lanes == 16 && total < uniform_below && j - i > 1 && j - i <= (size_t)phmm::kRaggedMaxSegs) {
-            launches.push_back(FpLaunch{i, j - i, -1});
+            bool tab = tab_on;
+            for (size_t q = i; q < j && tab; ++q)
+                if (rb->bins[q].rows_per_lane <= k4 && !tab_slots_of(rb->bins[q].rows_per_lane, run_max_hap)) tab = false;
+            launches.push_back(FpLaunch{i, j - i, -1, tab});
             i = j;
             continue;
         }
+        bool tab = tab_on && lanes == 16;
+        for (size_t q = i; q < j && tab; ++q)
+            if (!tab_slots_of(rb->bins[q].rows_per_lane, run_max_hap)) tab = false;
+        auto range_of = [&](const Bin &bn) {
+            if (tab) return bn.rows_per_lane <= k4 ? 0 : 1;
+            return phmm::ragged_range_of(lanes == 64 ? wide_rows(bn) : bn.rows_per_lane, lanes, rb->uniform_gop);
+        };
         for (size_t k = i; k < j;) {
-            const int range = phmm::ragged_range_of(lanes == 64 ? wide_rows(rb->bins[k]) : rb->bins[k].rows_per_lane, lanes, rb->uniform_gop);
+            const int range = range_of(rb->bins[k]);
             size_t e = k + 1;
-            while (e < j && e - k < (size_t)phmm::kRaggedMaxSegs &&
-                   phmm::ragged_range_of(lanes == 64 ? wide_rows(rb->bins[e]) : rb->bins[e].rows_per_lane, lanes, rb->uniform_gop) == range)
-                ++e;
-            launches.push_back(FpLaunch{k, e - k, lanes});
+            while (e < j && e - k < (size_t)phmm::kRaggedMaxSegs && range_of(rb->bins[e]) == range) ++e;
+            launches.push_back(FpLaunch{k, e - k, lanes, tab});
             k = e;
         }
         i = j;
@@ -222,10 +247,15 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
             uint32_t wg = 0, lds_words = 0;
             uint64_t total = 0;
             const bool uniform = L.lanes < 0;
+            uint32_t launch_max_hap = 0;
+            for (size_t q = 0; q < L.n; ++q) launch_max_hap = std::max(launch_max_hap, rb->bins[L.first + q].max_hap_len);
             for (size_t q = L.n; q-- > 0;) {
                 const Bin &sb = rb->bins[L.first + q];
                 phmm::RaggedSeg &sg = m.seg[m.n_seg++];
-                const int seg_lanes = uniform ? phmm::ragged_uniform_lanes_of(sb.rows_per_lane, rb->uniform_gop) : L.lanes;
+                const int seg_lanes = !uniform ? L.lanes
+                                      : L.tab  ? (sb.rows_per_lane <= phmm::tab_rows_at_four_waves(rb->uniform_gop) ? 16 : 32)
+                                               : phmm::ragged_uniform_lanes_of(sb.rows_per_lane, rb->uniform_gop);
+                sg.tab_slots = L.tab && seg_lanes == 16 ? tab_slots_of(sb.rows_per_lane, launch_max_hap) : 0u;
                 const uint32_t per_wg = seg_lanes == 64 ? 1u : (uint32_t)phmm::kBlockThreads / (uint32_t)seg_lanes;
                 sg.wg_first = wg;
                 sg.pos_first = sb.first;
@@ -245,10 +275,17 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
             a.rescue_list = rb->rescue_list.p;
             a.rescue_count = rb->rescue_count.p;
             if (L.lanes != 64 && total >= xcd_min && xcd_local) a.xcd_run_log2 = 6;
+            if (L.tab) {
+                a.hap_bases = rb->hap_bases.p;
+                a.hap_off = rb->hap_off.p;
+                a.tab_max_hap = launch_max_hap;
+            }
             if (uniform)
-                HIP_TRY(phmm::launch_systolic_ragged_uniform_f32(rb->uniform_gop, a, m, stream));
+                HIP_TRY(L.tab ? phmm::launch_systolic_ragged_tab_uniform_f32(rb->uniform_gop, a, m, stream)
+                              : phmm::launch_systolic_ragged_uniform_f32(rb->uniform_gop, a, m, stream));
             else
-                HIP_TRY(phmm::launch_systolic_ragged_f32(L.lanes, rb->uniform_gop, a, m, stream));
+                HIP_TRY(L.tab ? phmm::launch_systolic_ragged_tab_f32(rb->uniform_gop, a, m, stream)
+                              : phmm::launch_systolic_ragged_f32(L.lanes, rb->uniform_gop, a, m, stream));
         }
         else if (bin.rows_per_lane > 0) {
             // Few pairs: one pair per wave.  Four per wave would occupy count / 4 of the chip's 1024 SIMDs with one slow wave
@@ -260,10 +297,8 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
             const int k = lanes == 64 ? wide_rows(bin) : bin.rows_per_lane;
             // big four-pairs-per-wave launches: runs of 64 workgroups (1 024 pairs, a region or so) per XCD, see KernelArgs
             if (lanes == 16 && bin.count >= xcd_min && xcd_local) a.xcd_run_log2 = 6;
-            const char *tab = phmm_hook("PHMM_TAB");
-            const uint32_t tab_slots = tab && lanes == 16 && rb->uniform_gcp && rb->hap_bases.p && rb->hap_off.p
-                                           ? phmm::tab_slots_for(k, rb->uniform_gop, bin.max_hap_len) : 0u;
-            if (tab_slots >= 4) {
+            const uint32_t tab_slots = lanes == 16 ? tab_slots_of(k, bin.max_hap_len) : 0u;
+            if (tab_slots) {
                 a.hap_bases = rb->hap_bases.p;
                 a.hap_off = rb->hap_off.p;
                 a.tab_max_hap = bin.max_hap_len;

@@ -67,9 +67,10 @@ __host__ __device__ inline uint32_t tab_lds_bytes(int K, uint32_t slots, uint32_
 
 // UGO: one gap-open quality in the batch (pairhmm_systolic_ugo_sweep.inc); otherwise per-base gap-opens with deletion == insertion and
 // one gap-continuation quality (pairhmm_systolic_sweep.inc with UG = true: the Rovaca case with a PCR indel model).
+// n_slots: tables the workgroup's LDS holds (1..16; the launch sized the LDS with tab_lds_bytes for it).
 template <int K, bool UGO>
 __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t wg, uint32_t pos_first, uint32_t count, uint32_t *rescue_list,
-                                                   uint32_t *rescue_count)
+                                                   uint32_t *rescue_count, uint32_t n_slots)
 {
     using T = float;
     constexpr int G = 16;
@@ -87,7 +88,6 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
     const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
 
     // ---- LDS of the workgroup: the tables' quads, their tails (interleaved), the 16 pairs' haplotype entries, the 16 read ids ----
-    const uint32_t n_slots = a.tab_slots;
     const uint32_t tail_at = n_slots * (Q * 1024u);
     const uint32_t hap_at = tab_table_region_bytes(K, n_slots);
     const uint32_t hap_stride = tab_hap_bytes(a.tab_max_hap);
@@ -97,11 +97,11 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
     // ---- the haplotype: 16-bit entries (symbol * 256), entry 16 + d + (j - 1) for column j, d = the haplotype's offset in its dword.
     // 16 lanes x one aligned dword per round; dwords that do not touch the haplotype are not read (symbol 0).  A base outside
     // A, C, G, T makes the pair `dirty` (bases of the neighbours in the first and last dword count too: a false alarm costs speed only). ----
-    const uint32_t hoff = a.hap_off[h];
-    const uint32_t d = hoff & 3u;
+    const uintptr_t hap_at_mem = reinterpret_cast<uintptr_t>(a.hap_bases) + a.hap_off[h];
+    const uint32_t d = static_cast<uint32_t>(hap_at_mem & 3u);
     bool dirty = false;
     {
-        const uint8_t *src = a.hap_bases + (hoff - d);
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(hap_at_mem - d);
         if (lane < 8) reinterpret_cast<uint32_t *>(hapl)[lane] = 0;  // the 16 entries in front
         const uint32_t rounds = tab_hap_rounds(a.tab_max_hap);
         for (uint32_t it = 0; it < rounds; ++it) {
@@ -300,16 +300,19 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
         };
         // step t: issue the table reads of step t + 1 and the haplotype read of step t + 2, then compute with what the step before fetched
         uint32_t so_next;  // the entry of step t + 1
+#ifndef PHMM_TAB_EXPERIMENT
+#define PHMM_TAB_EXPERIMENT 0  // timing experiments (wrong results): 1 = no table reads in the loop, 2 = no haplotype reads either
+#endif
         auto step = [&](uint32_t t, bool odd, bool live) {
             if (odd) {
-                fetch(prB, so_next);
-                so_next = hp[t + 2];
+                if (PHMM_TAB_EXPERIMENT < 1 || t < 3) fetch(prB, so_next);
+                if (PHMM_TAB_EXPERIMENT < 2 || t < 3) so_next = hp[t + 2];
                 __builtin_amdgcn_sched_barrier(0);
                 if (live) compute(aM, aX, aY, bM, bX, bY, prA);
             }
             else {
-                fetch(prA, so_next);
-                so_next = hp[t + 2];
+                if (PHMM_TAB_EXPERIMENT < 1 || t < 3) fetch(prA, so_next);
+                if (PHMM_TAB_EXPERIMENT < 2 || t < 3) so_next = hp[t + 2];
                 __builtin_amdgcn_sched_barrier(0);
                 if (live) compute(bM, bX, bY, aM, aX, aY, prB);
             }

@@ -75,7 +75,10 @@ def test_pair_binning_sparse_lengths_take_the_comparison_sort_and_agree():
     b = Batch.from_lists(reads, haps)
     order, bins = capi.plan_bins(b)
     R, H = b.read_len[b.pair_read[order]].astype(int), b.hap_len[b.pair_hap[order]].astype(int)
-    key = [(_class(r, h), -h, int(p)) for r, h, p in zip(R, H, order)]
+    # the length key is the READ's longest haplotype (round 5: the pairs of a read stay together for the table kernels)
+    hr = np.zeros(b.n_reads, int)
+    np.maximum.at(hr, b.pair_read, b.hap_len[b.pair_hap].astype(int))
+    key = [(_class(r, h), -int(hr[q]), int(p)) for r, h, q, p in zip(R, H, b.pair_read[order], order)]
     assert key == sorted(key) and sum(c for _, _, c in bins) == b.n_pairs
 
 

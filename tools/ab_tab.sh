@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r5
-export PHMM_ENABLE_TEST_HOOKS=1
-PHMM_TAB=1 timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/r5/gputests_tab.log 2>&1
-tail -30 gpurun_out/r5/gputests_tab.log
+timeout -k 10 1000 python -m pytest tests -m gpu -q -x --deselect tests/test_bench_contract.py::test_device_line_carries_the_measured_traffic > gpurun_out/r5/gputests.log 2>&1
+tail -25 gpurun_out/r5/gputests.log
