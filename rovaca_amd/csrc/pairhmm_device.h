@@ -102,6 +102,7 @@ struct KernelArgs
     const uint32_t *hap_off;
     uint32_t tab_max_hap;
     uint32_t tab_slots;  // tables per workgroup (LDS)
+    uint32_t tab_max_read;  // longest read of the launch (read by the eight-lane experiment only: -DPHMM_EXPERIMENT_TAB8)
 };
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;
 constexpr int kTimelineStripes = 64, kTimelineWords = 8;
@@ -116,8 +117,12 @@ hipError_t launch_systolic_f32(int rows_per_lane, int lanes_per_pair, bool unifo
 // tab_slots_for says how many tables fit a workgroup at the kernel's occupancy (0: the class cannot take the table kernel).
 constexpr int kTabMaxRows = 16;
 // (registers: 7 K + 25 with one gap-open quality, 8 K + 25 with per-base gap-opens)
-// 16-lane classes up to this many rows per lane run the table sweep at four waves per SIMD (<= 128 registers); above, three
-constexpr int tab_rows_at_four_waves(bool uniform_gop) { return uniform_gop ? 14 : 12; }
+// Every class of the table sweep runs at four waves per SIMD: with the priors single-buffered the steady loop of 16 rows per lane
+// fits 128 registers in both arithmetic forms (what spills is the prologue and the bit-plane fallback, outside the loop)
+#ifndef PHMM_TAB_WAVES
+#define PHMM_TAB_WAVES 4  // (tools/build_tab_variant.sh: tuning and debugging)
+#endif
+constexpr int kTabWaves = PHMM_TAB_WAVES;
 // LDS a workgroup of a table kernel may use at `waves` per SIMD, and how many tables then fit next to the 16 haplotypes (0: none)
 uint32_t tab_lds_budget(int waves);
 uint32_t tab_slots_for(int rows_per_lane, uint32_t max_hap, uint32_t lds_budget);
@@ -143,12 +148,10 @@ struct RaggedArgs
     uint32_t n_seg, n_wg;  // classes, workgroups in all
     RaggedSeg seg[kRaggedMaxSegs];
 };
-// Ragged launches of the table sweep (pairhmm_kernels_ragged_tab.hip), as launch_systolic_ragged_f32 / _uniform_f32 below: several
-// rows-per-lane classes in one launch.  range 0: classes up to tab_rows_at_four_waves (one kernel at four waves per SIMD), 1: the
-// classes above (three waves).  The uniform-budget form holds range 0 as table sweeps and the classes above as 32-lane bit-plane
-// sweeps (RaggedSeg::lanes), all at four waves.  RaggedSeg::tab_slots per 16-lane class; KernelArgs::tab_max_hap for the launch.
+// Ragged launches of the table sweep (pairhmm_kernels_ragged_tab.hip), as launch_systolic_ragged_f32 below: several rows-per-lane
+// classes in one launch.  ONE kernel per arithmetic form holds every class (one register budget, four waves per SIMD), so launches of
+// any size take it.  RaggedSeg::tab_slots per class (RaggedSeg::lanes is not read); KernelArgs::tab_max_hap for the launch.
 hipError_t launch_systolic_ragged_tab_f32(bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
-hipError_t launch_systolic_ragged_tab_uniform_f32(bool uniform_gop, const KernelArgs &a, const RaggedArgs &m, hipStream_t s);
 // which ragged kernel a class belongs to (classes of one range share a kernel: the same occupancy target); -1: none
 int ragged_range_of(int rows_per_lane, int lanes_per_pair, bool uniform_gop);
 // uniform gap-continuation penalty and deletion == insertion gap-opens are required (the Rovaca case); uniform_gop as in launch_systolic_f32

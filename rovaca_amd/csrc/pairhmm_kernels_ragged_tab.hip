@@ -3,11 +3,10 @@
 // why).  Compiled twice, once per arithmetic form (-DPHMM_RAGGED_TAB_MODE=1: per-base gap-opens, the Rovaca case under a PCR indel
 // model; =2: one gap-open quality), so that the two halves build side by side.
 //
-// Kernels per form: the K ranges that share an occupancy target (classes up to tab_rows_at_four_waves: four waves per SIMD, 128
-// registers; the classes above: three), for launches of 2^18 pairs and more; and the uniform-budget kernel of chunk- and stage-sized
-// launches, ONE kernel at four waves per SIMD in which the classes above the border run as 32-lane bit-plane sweeps (about 100
-// registers) as they do in pairhmm_kernels_ragged.hip.  The LDS of a launch is the largest any of its classes needs; every class gets
-// as many table slots as fit it (RaggedSeg::tab_slots, set by the host).
+// One kernel per form: every class of the table sweep fits one register budget (128, four waves per SIMD), so -- unlike the bit-plane
+// sweeps, which need K ranges for big launches and a uniform-budget kernel with 32-lane classes for chunk- and stage-sized ones -- the
+// same kernel serves launches of every size.  The LDS of a launch is the largest any of its classes needs; every class gets as many
+// table slots as fit it (RaggedSeg::tab_slots, set by the host).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -38,24 +37,8 @@ __device__ __forceinline__ void ragged_tab_dispatch(uint32_t rows, const KernelA
     if constexpr (K < KHI) ragged_tab_dispatch<MODE, K + 1, KHI>(rows, a, wg, sg);
 }
 
-template <int MODE, int K, int KHI>
-__device__ __forceinline__ void ragged_tab_dispatch32(uint32_t rows, const KernelArgs &a, uint32_t wg, const RaggedSeg &sg)
-{
-    if (rows == (uint32_t)K) {
-        if constexpr (kUgo)
-            systolic_ugo_sweep<float, K, 32, 256>(a, wg, sg.pos_first, sg.count, a.rescue_list + sg.list_base, a.rescue_count + sg.queue);
-        else
-            systolic_sweep<float, K, true, 32, 256>(a, wg, sg.pos_first, sg.count, a.rescue_list + sg.list_base, a.rescue_count + sg.queue);
-        return;
-    }
-    if constexpr (K < KHI) ragged_tab_dispatch32<MODE, K + 1, KHI>(rows, a, wg, sg);
-}
-
-constexpr int kK4 = tab_rows_at_four_waves(kUgo);      // the last class at four waves per SIMD
-constexpr int kK32Min = (16 * kK4 + 1 + 31) / 32;      // rows per lane of the 32-lane classes above it
-
-template <int MODE, int KLO, int KHI>
-__global__ void __launch_bounds__(256, (KHI <= kK4 ? 4 : 3)) pairhmm_systolic_ragged_tab_kernel(KernelArgs a, RaggedArgs m)
+template <int MODE>
+__global__ void __launch_bounds__(256, kTabWaves) pairhmm_systolic_ragged_tab_kernel(KernelArgs a, RaggedArgs m)
 {
     const uint32_t b = xcd_local_workgroup(blockIdx.x, a.xcd_run_log2);
     if (b >= m.n_wg) return;  // (the XCD-local order rounds the grid up)
@@ -63,32 +46,16 @@ __global__ void __launch_bounds__(256, (KHI <= kK4 ? 4 : 3)) pairhmm_systolic_ra
     for (uint32_t i = 1; i < m.n_seg; ++i)
         if (b >= m.seg[i].wg_first) s = i;
     const RaggedSeg sg = m.seg[s];
-    ragged_tab_dispatch<MODE, KLO, KHI>(sg.rows, a, b - sg.wg_first, sg);
+    ragged_tab_dispatch<MODE, 1, kTabMaxRows>(sg.rows, a, b - sg.wg_first, sg);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256, 4) pairhmm_systolic_ragged_tab_uniform_kernel(KernelArgs a, RaggedArgs m)
-{
-    const uint32_t b = xcd_local_workgroup(blockIdx.x, a.xcd_run_log2);
-    if (b >= m.n_wg) return;
-    uint32_t s = 0;
-    for (uint32_t i = 1; i < m.n_seg; ++i)
-        if (b >= m.seg[i].wg_first) s = i;
-    const RaggedSeg sg = m.seg[s];
-    if (sg.lanes == 32u) {
-        ragged_tab_dispatch32<MODE, kK32Min, kMaxRowsPerLaneMid>(sg.rows, a, b - sg.wg_first, sg);
-        return;
-    }
-    ragged_tab_dispatch<MODE, 1, kK4>(sg.rows, a, b - sg.wg_first, sg);
-}
-
-// LDS of a launch: the most any of its classes needs -- a table class its tables and haplotype entries (and the planes of the
-// bit-plane sweep a workgroup with an N in a haplotype falls back to), a 32-lane class its planes
+// LDS of a launch: the most any of its classes needs -- its tables and haplotype entries, and the planes of the bit-plane sweep a
+// workgroup with an N in a haplotype falls back to
 static size_t ragged_tab_lds(const KernelArgs &a, const RaggedArgs &m)
 {
     size_t bytes = (size_t)16 * a.lds_words_per_group * sizeof(uint32_t);
     for (uint32_t i = 0; i < m.n_seg; ++i)
-        if (m.seg[i].lanes != 32u) bytes = std::max<size_t>(bytes, tab_lds_bytes((int)m.seg[i].rows, m.seg[i].tab_slots, a.tab_max_hap));
+        bytes = std::max<size_t>(bytes, tab_lds_bytes((int)m.seg[i].rows, m.seg[i].tab_slots, a.tab_max_hap));
     return bytes;
 }
 
@@ -110,35 +77,11 @@ hipError_t launch_systolic_ragged_tab_ug_f32(const KernelArgs &a, const RaggedAr
 {
     if (m.n_seg == 0 || m.n_wg == 0) return hipSuccess;
     if (m.n_seg > (uint32_t)kRaggedMaxSegs || !a.hap_bases || !a.hap_off) return hipErrorInvalidValue;
-    const bool low = (int)m.seg[0].rows <= kK4;
     for (uint32_t i = 0; i < m.n_seg; ++i) {
         const RaggedSeg &g = m.seg[i];
-        if (g.rows < 1 || g.rows > (uint32_t)kTabMaxRows || ((int)g.rows <= kK4) != low || g.tab_slots < 1 || g.tab_slots > 16) return hipErrorInvalidValue;
+        if (g.rows < 1 || g.rows > (uint32_t)kTabMaxRows || g.tab_slots < 1 || g.tab_slots > 16) return hipErrorInvalidValue;
     }
-    const size_t shmem = ragged_tab_lds(a, m);
-    if (low)
-        hipLaunchKernelGGL((pairhmm_systolic_ragged_tab_kernel<kMode, 1, kK4>), dim3(ragged_grid(a, m)), dim3(256), shmem, s, a, m);
-    else
-        hipLaunchKernelGGL((pairhmm_systolic_ragged_tab_kernel<kMode, kK4 + 1, kTabMaxRows>), dim3(ragged_grid(a, m)), dim3(256), shmem, s, a, m);
-    return hipGetLastError();
-}
-
-#if PHMM_RAGGED_TAB_MODE == 2
-hipError_t launch_systolic_ragged_tab_uniform_ugo_f32(const KernelArgs &a, const RaggedArgs &m, hipStream_t s)
-#else
-hipError_t launch_systolic_ragged_tab_uniform_ug_f32(const KernelArgs &a, const RaggedArgs &m, hipStream_t s)
-#endif
-{
-    if (m.n_seg == 0 || m.n_wg == 0) return hipSuccess;
-    if (m.n_seg > (uint32_t)kRaggedMaxSegs || !a.hap_bases || !a.hap_off) return hipErrorInvalidValue;
-    for (uint32_t i = 0; i < m.n_seg; ++i) {
-        const RaggedSeg &g = m.seg[i];
-        const bool ok = g.lanes == 16u   ? (g.rows >= 1 && (int)g.rows <= kK4 && g.tab_slots >= 1 && g.tab_slots <= 16)
-                        : g.lanes == 32u ? (g.rows >= (uint32_t)kK32Min && g.rows <= (uint32_t)kMaxRowsPerLaneMid)
-                                         : false;
-        if (!ok) return hipErrorInvalidValue;
-    }
-    hipLaunchKernelGGL((pairhmm_systolic_ragged_tab_uniform_kernel<kMode>), dim3(ragged_grid(a, m)), dim3(256), ragged_tab_lds(a, m), s, a, m);
+    hipLaunchKernelGGL((pairhmm_systolic_ragged_tab_kernel<kMode>), dim3(ragged_grid(a, m)), dim3(256), ragged_tab_lds(a, m), s, a, m);
     return hipGetLastError();
 }
 

@@ -130,7 +130,7 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
     const bool tab_on = rb->uniform_gcp && rb->hap_bases.p && rb->hap_off.p && !phmm_hook("PHMM_NO_TAB");
     auto tab_slots_of = [&](int k16, uint32_t max_hap) -> uint32_t {
         if (!tab_on || k16 < 1 || k16 > phmm::kTabMaxRows) return 0u;
-        const uint32_t n = phmm::tab_slots_for(k16, max_hap, phmm::tab_lds_budget(k16 <= phmm::tab_rows_at_four_waves(rb->uniform_gop) ? 4 : 3));
+        const uint32_t n = phmm::tab_slots_for(k16, max_hap, phmm::tab_lds_budget(phmm::kTabWaves));
         if (const char *f = phmm_hook("PHMM_TAB_SLOTS"))  // tests: few tables per workgroup, so that workgroups sweep in rounds
             return n ? std::min<uint32_t>(n, (uint32_t)std::max(1, atoi(f))) : 0u;
         return n >= phmm::kTabMinSlots ? n : 0u;
@@ -172,27 +172,29 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
         // sized by the run's longest haplotype)
         uint32_t run_max_hap = 0;
         for (size_t q = i; q < j; ++q) run_max_hap = std::max(run_max_hap, rb->bins[q].max_hap_len);
-        const int k4 = phmm::tab_rows_at_four_waves(rb->uniform_gop);
-        if (lanes == 16 && total < uniform_below && j - i > 1 && j - i <= (size_t)phmm::kRaggedMaxSegs) {
-            bool tab = tab_on;
-            for (size_t q = i; q < j && tab; ++q)
-                if (rb->bins[q].rows_per_lane <= k4 && !tab_slots_of(rb->bins[q].rows_per_lane, run_max_hap)) tab = false;
-            launches.push_back(FpLaunch{i, j - i, -1, tab});
-            i = j;
-            continue;
-        }
+        // as table sweeps all classes share one kernel at one register budget, whatever the size of the run: one launch (in pieces of
+        // kRaggedMaxSegs classes)
         bool tab = tab_on && lanes == 16;
         for (size_t q = i; q < j && tab; ++q)
             if (!tab_slots_of(rb->bins[q].rows_per_lane, run_max_hap)) tab = false;
-        auto range_of = [&](const Bin &bn) {
-            if (tab) return bn.rows_per_lane <= k4 ? 0 : 1;
-            return phmm::ragged_range_of(lanes == 64 ? wide_rows(bn) : bn.rows_per_lane, lanes, rb->uniform_gop);
-        };
+        if (tab) {
+            for (size_t k = i; k < j; k += (size_t)phmm::kRaggedMaxSegs)
+                launches.push_back(FpLaunch{k, std::min(j - k, (size_t)phmm::kRaggedMaxSegs), 16, true});
+            i = j;
+            continue;
+        }
+        if (lanes == 16 && total < uniform_below && j - i > 1 && j - i <= (size_t)phmm::kRaggedMaxSegs) {
+            launches.push_back(FpLaunch{i, j - i, -1, false});
+            i = j;
+            continue;
+        }
         for (size_t k = i; k < j;) {
-            const int range = range_of(rb->bins[k]);
+            const int range = phmm::ragged_range_of(lanes == 64 ? wide_rows(rb->bins[k]) : rb->bins[k].rows_per_lane, lanes, rb->uniform_gop);
             size_t e = k + 1;
-            while (e < j && e - k < (size_t)phmm::kRaggedMaxSegs && range_of(rb->bins[e]) == range) ++e;
-            launches.push_back(FpLaunch{k, e - k, lanes, tab});
+            while (e < j && e - k < (size_t)phmm::kRaggedMaxSegs &&
+                   phmm::ragged_range_of(lanes == 64 ? wide_rows(rb->bins[e]) : rb->bins[e].rows_per_lane, lanes, rb->uniform_gop) == range)
+                ++e;
+            launches.push_back(FpLaunch{k, e - k, lanes, false});
             k = e;
         }
         i = j;
@@ -252,9 +254,7 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
             for (size_t q = L.n; q-- > 0;) {
                 const Bin &sb = rb->bins[L.first + q];
                 phmm::RaggedSeg &sg = m.seg[m.n_seg++];
-                const int seg_lanes = !uniform ? L.lanes
-                                      : L.tab  ? (sb.rows_per_lane <= phmm::tab_rows_at_four_waves(rb->uniform_gop) ? 16 : 32)
-                                               : phmm::ragged_uniform_lanes_of(sb.rows_per_lane, rb->uniform_gop);
+                const int seg_lanes = uniform ? phmm::ragged_uniform_lanes_of(sb.rows_per_lane, rb->uniform_gop) : L.lanes;
                 sg.tab_slots = L.tab && seg_lanes == 16 ? tab_slots_of(sb.rows_per_lane, launch_max_hap) : 0u;
                 const uint32_t per_wg = seg_lanes == 64 ? 1u : (uint32_t)phmm::kBlockThreads / (uint32_t)seg_lanes;
                 sg.wg_first = wg;
@@ -281,8 +281,7 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
                 a.tab_max_hap = launch_max_hap;
             }
             if (uniform)
-                HIP_TRY(L.tab ? phmm::launch_systolic_ragged_tab_uniform_f32(rb->uniform_gop, a, m, stream)
-                              : phmm::launch_systolic_ragged_uniform_f32(rb->uniform_gop, a, m, stream));
+                HIP_TRY(phmm::launch_systolic_ragged_uniform_f32(rb->uniform_gop, a, m, stream));
             else
                 HIP_TRY(L.tab ? phmm::launch_systolic_ragged_tab_f32(rb->uniform_gop, a, m, stream)
                               : phmm::launch_systolic_ragged_f32(L.lanes, rb->uniform_gop, a, m, stream));
@@ -303,6 +302,7 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
                 a.hap_off = rb->hap_off.p;
                 a.tab_max_hap = bin.max_hap_len;
                 a.tab_slots = tab_slots;
+                a.tab_max_read = bin.max_read_len;
                 HIP_TRY(phmm::launch_systolic_tab_f32(k, rb->uniform_gop, a, stream));
             }
             else

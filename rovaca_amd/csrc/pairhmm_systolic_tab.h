@@ -13,7 +13,7 @@
 // gets a table  prior[row][symbol]  for the four symbols A, C, G, T in LDS -- 16 bytes per row, K x 256 bytes per read -- laid out so
 // that one `ds_read_b128` returns the priors of four consecutive rows of a lane for the symbol of its column:
 //
-//      quads:   slot * Q * 1024 + q * 1024 + symbol * 256 + lane * 16       (rows 4q .. 4q+3 of `lane`)
+//      quads:   slot * Q * 1280 + q * 1280 + symbol * 256 + lane * 16       (rows 4q .. 4q+3 of `lane`; five symbols, below)
 //      halves:  symbol * 256 + (slot & 1) * 128 + lane * 8  in block slot/2  (K mod 4 == 2: the last two rows; two tables interleave)
 //      singles: symbol * 256 + (slot & 3) * 64 + lane * 4   in block slot/4  (K mod 4 == 1: the last row; four tables interleave)
 //
@@ -54,11 +54,13 @@ template <int K> struct TabShape
 // (16 lanes x 4 bases) that cover the haplotype, its offset in its first dword, and the 15 + 2 + 1 columns the sweep looks past its end
 __host__ __device__ inline uint32_t tab_hap_rounds(uint32_t max_hap) { return (max_hap + 21u + 63u) / 64u; }
 __host__ __device__ inline uint32_t tab_hap_bytes(uint32_t max_hap) { return 2u * (16u + 64u * tab_hap_rounds(max_hap)); }
-// LDS of a workgroup: `slots` tables of K rows, the 16 pairs' haplotype entries, the 16 read ids
+// LDS of a workgroup: `slots` tables of K rows and FIVE symbols (kTabSymStride bytes apart; the fifth is all zeros, below), the 16
+// pairs' haplotype entries, the 16 read ids
+constexpr uint32_t kTabSyms = 5, kTabSymStride = 256, kTabQuadStride = kTabSyms * kTabSymStride;
 __host__ __device__ inline uint32_t tab_table_region_bytes(int K, uint32_t slots)
 {
     const int rem = K % 4, quads = rem == 3 ? (K + 3) / 4 : K / 4, tail = rem == 3 ? 0 : rem;
-    return slots * quads * 1024u + (tail == 2 ? (slots + 1) / 2 * 1024u : tail == 1 ? (slots + 3) / 4 * 1024u : 0u);
+    return slots * quads * kTabQuadStride + (tail == 2 ? (slots + 1) / 2 * kTabQuadStride : tail == 1 ? (slots + 3) / 4 * kTabQuadStride : 0u);
 }
 __host__ __device__ inline uint32_t tab_lds_bytes(int K, uint32_t slots, uint32_t max_hap)
 {
@@ -88,31 +90,51 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
     const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
 
     // ---- LDS of the workgroup: the tables' quads, their tails (interleaved), the 16 pairs' haplotype entries, the 16 read ids ----
-    const uint32_t tail_at = n_slots * (Q * 1024u);
+    const uint32_t tail_at = n_slots * (Q * kTabQuadStride);
     const uint32_t hap_at = tab_table_region_bytes(K, n_slots);
     const uint32_t hap_stride = tab_hap_bytes(a.tab_max_hap);
     uint8_t *hapl = lds_raw + hap_at + grp * hap_stride;
     uint32_t *rid = reinterpret_cast<uint32_t *>(lds_raw + hap_at + 16u * hap_stride);
 
     // ---- the haplotype: 16-bit entries (symbol * 256), entry 16 + d + (j - 1) for column j, d = the haplotype's offset in its dword.
-    // 16 lanes x one aligned dword per round; dwords that do not touch the haplotype are not read (symbol 0).  A base outside
-    // A, C, G, T makes the pair `dirty` (bases of the neighbours in the first and last dword count too: a false alarm costs speed only). ----
-    const uintptr_t hap_at_mem = reinterpret_cast<uintptr_t>(a.hap_bases) + a.hap_off[h];
-    const uint32_t d = static_cast<uint32_t>(hap_at_mem & 3u);
+    // 16 lanes x one aligned dword per round.  Every entry that is NOT a column of the haplotype -- the 16 + d in front, everything
+    // behind column H -- names the ZERO symbol, whose priors are 0 for every row: a lane that computes such a column leaves the column-0
+    // state of its rows as it is (M = t * 0, X chains down from the boundary's 0 through M = 0, Y = Y * p_yy + 0 keeps 0 and, in a
+    // boundary replica with p_yy = 1, init), and adds 0 to both sums.  So the sweep needs no predicate at all: lanes "start" before
+    // their first column and run on behind their last one, and pairs with a shorter haplotype than the wave's longest idle exactly.
+    // A base outside A, C, G, T makes the pair `dirty`. ----
+    const uint32_t hoff = a.hap_off[h];
+    const uint32_t d = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(a.hap_bases) + hoff) & 3u);  // (the table may begin at any byte)
     bool dirty = false;
     {
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(hap_at_mem - d);
-        if (lane < 8) reinterpret_cast<uint32_t *>(hapl)[lane] = 0;  // the 16 entries in front
+        constexpr uint32_t kZero = 4u * kTabSymStride;
+        const uint8_t *__restrict__ src = a.hap_bases + hoff - d;  // dword-aligned (arithmetic on the kernel argument: global loads, not flat)
+        if (lane < 8) reinterpret_cast<uint32_t *>(hapl)[lane] = kZero | (kZero << 16);  // the 16 entries in front
         const uint32_t rounds = tab_hap_rounds(a.tab_max_hap);
         for (uint32_t it = 0; it < rounds; ++it) {
-            const uint32_t i = it * 16u + lane;  // dword of the haplotype's span
-            uint32_t w = 0x41414141u;
-            if (4u * i + 3u >= d && 4u * i < d + H) w = *reinterpret_cast<const uint32_t *>(src + 4u * i);
-            const uint32_t x = (w >> 1) & 0x03030303u;  // A 0, C 1, T 2, G 3 in every byte (ASCII bits 1-2)
-            dirty = dirty || __builtin_amdgcn_perm(0u, 0x47544341u, x) != w;  // the four codes back to "ACTG": any other byte differs
+            const uint32_t i = it * 16u + lane;  // dword of the haplotype's span: bytes 4 i .. 4 i + 3, of which [d, d + H) are the haplotype's
+            const uint32_t b0 = 4u * i;
             uint2 e;
-            e.x = ((x & 0xFFu) << 8) | ((x & 0xFF00u) << 16);
-            e.y = (((x >> 16) & 0xFFu) << 8) | (((x >> 16) & 0xFF00u) << 16);
+            e.x = e.y = kZero | (kZero << 16);
+            if (b0 + 3u >= d && b0 < d + H) {
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(src + b0);
+                const uint32_t x = (w >> 1) & 0x03030303u;                         // A 0, C 1, T 2, G 3 in every byte (ASCII bits 1-2)
+                const uint32_t back = __builtin_amdgcn_perm(0u, 0x47544341u, x);  // the four codes back to "ACTG": any other byte differs
+                const uint32_t e0 = (x & 0xFFu) << 8, e1 = (x & 0xFF00u), e2 = (x >> 8) & 0xFF00u, e3 = (x >> 16) & 0xFF00u;
+                if (b0 >= d && b0 + 3u < d + H) {  // all four bytes are columns
+                    dirty = dirty || back != w;
+                    e.x = e0 | (e1 << 16);
+                    e.y = e2 | (e3 << 16);
+                }
+                else {
+                    const bool v0 = b0 >= d && b0 < d + H, v1 = b0 + 1u >= d && b0 + 1u < d + H, v2 = b0 + 2u >= d && b0 + 2u < d + H,
+                               v3 = b0 + 3u >= d && b0 + 3u < d + H;
+                    const uint32_t m = (v0 ? 0xFFu : 0u) | (v1 ? 0xFF00u : 0u) | (v2 ? 0xFF0000u : 0u) | (v3 ? 0xFF000000u : 0u);
+                    dirty = dirty || ((back ^ w) & m) != 0u;
+                    e.x = (v0 ? e0 : kZero) | ((v1 ? e1 : kZero) << 16);
+                    e.y = (v2 ? e2 : kZero) | ((v3 ? e3 : kZero) << 16);
+                }
+            }
             *reinterpret_cast<uint2 *>(hapl + 2u * (16u + 4u * i)) = e;
         }
     }
@@ -179,44 +201,58 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
     for (uint32_t base = 0; base < n_tables; base += n_slots) {
         const bool act = valid && slot >= base && slot - base < n_slots;
         const uint32_t sl = act ? slot - base : 0u;
-        uint8_t *quads = lds_raw + sl * (Q * 1024u) + lane * 16u;
-        uint8_t *tails = lds_raw + tail_at + (TAIL == 2 ? (sl >> 1) * 1024u + (sl & 1u) * 128u + lane * 8u : (sl >> 2) * 1024u + (sl & 3u) * 64u + lane * 4u);
+        uint8_t *quads = lds_raw + sl * (Q * kTabQuadStride) + lane * 16u;
+        uint8_t *tails = lds_raw + tail_at + (TAIL == 2 ? (sl >> 1) * kTabQuadStride + (sl & 1u) * 128u + lane * 8u : (sl >> 2) * kTabQuadStride + (sl & 3u) * 64u + lane * 4u);
         if (base) __syncthreads();  // the round before has read its tables
         if (act && leader) {
-            // the read's table: symbol code s (ASCII bits 1-2: A 0, C 1, T 2, G 3) -> read class (A 0, C 1, G 2, T 3); a read N matches all
-            T hi[K], lo[K];
-            uint32_t cls[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
+            // The read's table, four rows at a time (few registers live: this runs with the sweep's per-row constants already loaded).
+            // Symbol code s (ASCII bits 1-2: A 0, C 1, T 2, G 3) -> read class (A 0, C 1, G 2, T 3); a read N matches all; the fifth
+            // symbol (not a column of the haplotype) and the boundary replicas are 0.
+            auto row_entry = [&](int k, T &hi, T &lo, uint32_t &cls) {
                 const int row = static_cast<int>(lane) * K + k - pad;
-                cls[k] = 5, hi[k] = 0, lo[k] = 0;  // boundary replica: prior 0 kills M
-                if (row >= 0) {
+                cls = 5, hi = 0, lo = 0;
+                if (k < K && row >= 0) {
                     const uint32_t at = roff + static_cast<uint32_t>(row);
                     const T dist = ph2pr[a.read_qual[at] & 127u];
-                    hi[k] = static_cast<T>(1.0) - dist;
-                    lo[k] = Num<T>::div3(dist);
-                    cls[k] = read_class(a.read_bases[at]);
+                    hi = static_cast<T>(1.0) - dist;
+                    lo = Num<T>::div3(dist);
+                    cls = read_class(a.read_bases[at]);
                 }
-            }
-            auto sel = [&](int k, uint32_t s) -> T {
-                if (k >= K) return 0;
+            };
+            auto pick = [](T hi, T lo, uint32_t cls, uint32_t s) -> T {
+                if (s == 4u) return 0;
                 const uint32_t c = s == 2u ? 3u : s == 3u ? 2u : s;
-                return (cls[k] == c || cls[k] == 4u) ? hi[k] : lo[k];
+                return (cls == c || cls == 4u) ? hi : lo;
             };
 #pragma unroll
-            for (uint32_t s = 0; s < 4; ++s) {
+            for (int q = 0; q < Q; ++q) {
+                T hi[4], lo[4];
+                uint32_t cls[4];
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
+                for (int j = 0; j < 4; ++j) row_entry(4 * q + j, hi[j], lo[j], cls[j]);
+#pragma unroll
+                for (uint32_t s = 0; s < kTabSyms; ++s) {
                     float4 v;
-                    v.x = sel(4 * q, s), v.y = sel(4 * q + 1, s), v.z = sel(4 * q + 2, s), v.w = sel(4 * q + 3, s);
-                    *reinterpret_cast<float4 *>(quads + q * 1024 + s * 256u) = v;
+                    v.x = pick(hi[0], lo[0], cls[0], s), v.y = pick(hi[1], lo[1], cls[1], s), v.z = pick(hi[2], lo[2], cls[2], s),
+                    v.w = pick(hi[3], lo[3], cls[3], s);
+                    *reinterpret_cast<float4 *>(quads + q * kTabQuadStride + s * kTabSymStride) = v;
                 }
-                if constexpr (TAIL == 2) {
-                    float2 v;
-                    v.x = sel(4 * Q, s), v.y = sel(4 * Q + 1, s);
-                    *reinterpret_cast<float2 *>(tails + s * 256u) = v;
+            }
+            if constexpr (TAIL != 0) {
+                T hi[2], lo[2];
+                uint32_t cls[2];
+                row_entry(4 * Q, hi[0], lo[0], cls[0]);
+                row_entry(4 * Q + 1, hi[1], lo[1], cls[1]);  // (TAIL == 1: row K, which row_entry leaves at 0)
+#pragma unroll
+                for (uint32_t s = 0; s < kTabSyms; ++s) {
+                    if constexpr (TAIL == 2) {
+                        float2 v;
+                        v.x = pick(hi[0], lo[0], cls[0], s), v.y = pick(hi[1], lo[1], cls[1], s);
+                        *reinterpret_cast<float2 *>(tails + s * kTabSymStride) = v;
+                    }
+                    else
+                        *reinterpret_cast<float *>(tails + s * kTabSymStride) = pick(hi[0], lo[0], cls[0], s);
                 }
-                if constexpr (TAIL == 1) *reinterpret_cast<float *>(tails + s * 256u) = sel(4 * Q, s);
             }
         }
         __syncthreads();  // tables (and, the first time, the haplotype entries) are read by other lanes than wrote them
@@ -227,10 +263,6 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
         Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
         Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
         Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
-        uint32_t Tmin = Tg;
-        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 16));
-        Tmin = min(Tmin, (uint32_t)__shfl_xor((int)Tmin, 32));
-        Tmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmin);
         if (Tmax == 0) continue;  // none of the wave's four pairs is in this round
 
         T M[K], X[K], Y[K];
@@ -247,12 +279,12 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
         }
         T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
         T sumM = 0, sumX = 0;
-        T prA[K], prB[K];  // priors of this step / of the next one (the roles swap every step, like the two row-above sets)
-        auto fetch = [&](T(&pr)[K], uint32_t so) {
+        T pr[K];  // the priors of the step in hand; pass 1 uses them, and the next step's are fetched into the same registers behind it
+        auto fetch = [&](uint32_t so) {
             const uint8_t *tq = quads + so;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const float4 v = *reinterpret_cast<const float4 *>(tq + q * 1024);
+            for (int q = Q - 1; q >= 0; --q) {  // (pass 1 walks bottom-up: the last rows are needed first)
+                const float4 v = *reinterpret_cast<const float4 *>(tq + q * kTabQuadStride);
                 pr[4 * q] = v.x;
                 if (4 * q + 1 < K) pr[4 * q + 1] = v.y;
                 if (4 * q + 2 < K) pr[4 * q + 2] = v.z;
@@ -265,9 +297,12 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
             }
             if constexpr (TAIL == 1) pr[4 * Q] = *reinterpret_cast<const float *>(tails + so);
         };
-        // one anti-diagonal with the priors `pr`.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it
-        // at this column.  The arithmetic is the bit-plane sweeps', statement for statement.
-        auto compute = [&](T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0, const T(&pr)[K]) {
+        // One anti-diagonal.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it at this column.  The
+        // arithmetic is the bit-plane sweeps', statement for statement.  Pass 1 (bottom row first, in place) is the only user of the
+        // priors; the table reads of the next step are issued right behind it and land while pass 2 (top row first: the insertion state
+        // chains down through the new M and X) runs.
+        uint32_t so_next;  // the haplotype entry of step t + 1
+        auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
             uM0 = dpp_shr1<G>(uM0, M[K - 1]);
             uX0 = dpp_shr1<G>(uX0, X[K - 1]);
             uY0 = dpp_shr1<G>(uY0, Y[K - 1]);
@@ -284,6 +319,16 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
                 M[k] = tt * pr[k];
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef PHMM_TAB_DEBUG_WAIT_BEFORE_FETCH
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_s_nop(4);
+#endif
+            fetch(so_next);
+            so_next = hp[t + 2];
+#ifdef PHMM_TAB_DEBUG_WAIT_AFTER_FETCH
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
             T uM = uM0, uX = uX0;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -298,42 +343,14 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
             sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
             sumX = sumX + X[K - 1];
         };
-        // step t: issue the table reads of step t + 1 and the haplotype read of step t + 2, then compute with what the step before fetched
-        uint32_t so_next;  // the entry of step t + 1
-#ifndef PHMM_TAB_EXPERIMENT
-#define PHMM_TAB_EXPERIMENT 0  // timing experiments (wrong results): 1 = no table reads in the loop, 2 = no haplotype reads either
-#endif
-        auto step = [&](uint32_t t, bool odd, bool live) {
-            if (odd) {
-                if (PHMM_TAB_EXPERIMENT < 1 || t < 3) fetch(prB, so_next);
-                if (PHMM_TAB_EXPERIMENT < 2 || t < 3) so_next = hp[t + 2];
-                __builtin_amdgcn_sched_barrier(0);
-                if (live) compute(aM, aX, aY, bM, bX, bY, prA);
-            }
-            else {
-                if (PHMM_TAB_EXPERIMENT < 1 || t < 3) fetch(prA, so_next);
-                if (PHMM_TAB_EXPERIMENT < 2 || t < 3) so_next = hp[t + 2];
-                __builtin_amdgcn_sched_barrier(0);
-                if (live) compute(bM, bX, bY, aM, aX, aY, prB);
-            }
-        };
-        // Steps go in (odd, even) couples everywhere so that the two register sets and the two prior sets swap roles without a move:
-        // the fill (steps 1..16, lane l starts at step l + 1), the steady state (every lane of all four pairs has work, no predicate)
-        // and the drain (pairs with a shorter haplotype than the wave's longest drop out; may run one dead step past Tmax).
-        uint32_t t = 1;
-        fetch(prA, hp[1]);
+        // Steps go in (odd, even) couples so that the two row-above sets swap roles without a move.  No fill, no drain, no predicate:
+        // what a lane computes outside its haplotype's columns changes nothing (the zero symbol, above); the loop may run one step past
+        // the wave's last.
+        fetch(hp[1]);
         so_next = hp[2];
-        for (; t <= (uint32_t)G; t += 2) {
-            step(t, true, (t > lane) && (t <= Tg));
-            step(t + 1, false, (t + 1 > lane) && (t + 1 <= Tg));
-        }
-        for (; t + 1 <= Tmin; t += 2) {
-            step(t, true, true);
-            step(t + 1, false, true);
-        }
-        for (; t <= Tmax; t += 2) {
-            step(t, true, t <= Tg);
-            step(t + 1, false, t + 1 <= Tg);
+        for (uint32_t t = 1; t <= Tmax; t += 2) {
+            step(t, aM, aX, aY, bM, bX, bY);
+            step(t + 1, bM, bX, bY, aM, aX, aY);
         }
         if (act && lane == G - 1) {
             const T res = sumM + sumX;

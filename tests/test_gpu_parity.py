@@ -668,9 +668,15 @@ def test_ragged_launches_are_the_per_class_launches(engine, lanes, pcr_model, mo
             assert np.array_equal(l10, l10_0, equal_nan=True)
             assert int(st.n_rescued) == int(st0.n_rescued) > 0
         assert int(st1.n_launches) == 1 and int(st4.n_launches) <= 3 < int(st0.n_launches)
-        # (one pair per wave: every class fits one kernel's budget anyway; four per wave: the table sweeps have two budgets -- four
-        # waves per SIMD up to 14 / 12 rows per lane, three above -- where the bit-plane sweeps they replaced in round 5 had three)
-        assert int(st4.n_launches) == (1 if lanes == 64 else 2)
+        # (one pair per wave: every class fits one kernel's budget anyway; four per wave: so does every class of the table sweep that
+        # replaced the bit-plane sweeps in round 5 -- those needed three kernels of different budgets: PHMM_NO_TAB below)
+        assert int(st4.n_launches) == 1
+        monkeypatch.setenv("PHMM_NO_TAB", "1")
+        monkeypatch.setenv("PHMM_RAGGED_UNIFORM_BELOW", "0")
+        raw6, l10_6, st6 = engine.compute(b, prep=prep)
+        monkeypatch.delenv("PHMM_NO_TAB")
+        monkeypatch.delenv("PHMM_RAGGED_UNIFORM_BELOW")
+        assert np.array_equal(raw6.view(np.uint32), raw0.view(np.uint32)) and int(st6.n_launches) == (1 if lanes == 64 else 3)
     # and the oracle, on a sample (the batch prepared on the host the same way)
     if pcr_model == 0:
         k = rng.choice(b.n_pairs, 400, replace=False)
