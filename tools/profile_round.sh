@@ -8,11 +8,16 @@ for c in c2 c3 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$c -o $c -- python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/bench_$c.log 2>&1
   tail -1 $OUT/bench_$c.log | cut -c1-160
 done
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -o pmc -- python3 bench.py --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/pmc_$tag.log 2>&1
   echo "pmc $grp done"
 done
+# the clock the chip holds under the hot kernel (MI355X_MICROARCH.md, DVFS give-back: GRBM_GUI_ACTIVE / 8 / kernel wall time), with and
+# without the table sweep: one counter next to the kernel trace that gives each dispatch's duration
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/clk_c2 -o clk -- python3 bench.py --config c2 --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/clk_c2.log 2>&1
+PHMM_ENABLE_TEST_HOOKS=1 PHMM_NO_TAB=1 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/clk_c2_notab -o clk -- python3 bench.py --config c2 --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/clk_c2_notab.log 2>&1
+echo "clock passes done"
 # the same batch through the general kernel (per-base gap-opens: what a run under the default PCR model takes)
 export PHMM_ENABLE_TEST_HOOKS=1 PHMM_NO_UNIFORM_GOP=1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES"; do

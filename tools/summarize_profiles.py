@@ -63,6 +63,31 @@ if "SQ_INSTS_VALU" in mean and "SQ_WAVES" in mean:
     for ghz in (2.05,):
         lines.append("         cycles per VALU instruction per SIMD at %.2f GHz over %.3f ms: %.2f"
                      % (ghz, avg_ms, avg_ms * 1e-3 * ghz * 1e9 * 1024 / mean["SQ_INSTS_VALU"]))
+def effective_clock(sub):
+    """median over the sweep dispatches of GRBM_GUI_ACTIVE / 8 / duration (GHz), and the kernel's name"""
+    dur, gui, name = {}, {}, None
+    for f in glob.glob(os.path.join(src, sub, "*kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            if "pairhmm_systolic" in r["Kernel_Name"]:
+                dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                name = r["Kernel_Name"].replace("void ", "").split("(")[0]
+    for f in glob.glob(os.path.join(src, sub, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Dispatch_Id"] in dur:
+                gui[r["Dispatch_Id"]] = gui.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    q = sorted(gui[k] / 8.0 / dur[k] for k in gui if dur[k] > 0)
+    return (q[len(q) // 2] if q else None), name, (sorted(dur.values())[len(dur) // 2] / 1e6 if dur else None)
+
+
+clk, clk_name, clk_ms = effective_clock("clk_c2")
+clk0, clk0_name, clk0_ms = effective_clock("clk_c2_notab")
+if clk:
+    lines += ["", "effective clock under the hot kernel (GRBM_GUI_ACTIVE / 8 / dispatch duration, median over the dispatches of a counter pass):",
+              "  %s: %.3f GHz (%.3f ms per dispatch in that pass)" % (clk_name, clk, clk_ms)]
+    if clk0:
+        lines.append("  %s (PHMM_NO_TAB=1, the bit-plane kernel of rounds 1-4): %.3f GHz (%.3f ms)" % (clk0_name, clk0, clk0_ms))
+    if "SQ_INSTS_VALU" in mean:
+        lines.append("  -> %.2f cycles per VALU wave-instruction per SIMD at that clock" % (clk_ms * 1e-3 * clk * 1e9 * 1024 / mean["SQ_INSTS_VALU"]))
 open(os.path.join(dst, "%s_c2_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
 if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     sys.path.insert(0, ROOT)
@@ -100,7 +125,9 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
                "_note": "bytes per launch of %s on config c2: 2 x FETCH_SIZE (gfx950 correction, upper bound) + WRITE_SIZE, "
                         "from profiles/%s_c2_pmc_summary.txt" % (hot["Name"].replace("void ", "").split("(")[0], tag),
                "c2_fetch_raw_bytes": int(fetch), "c2_write_bytes": int(write),
-               "c2_valu_wave_instructions": int(mean.get("SQ_INSTS_VALU", 0)), "c2_kernel": hot["Name"].replace("void ", "").split("(")[0]},
+               "c2_valu_wave_instructions": int(mean.get("SQ_INSTS_VALU", 0)), "c2_kernel": hot["Name"].replace("void ", "").split("(")[0],
+               "c2_lds_wave_instructions": int(mean.get("SQ_INSTS_LDS", 0)), "c2_effective_clock_ghz": round(clk, 3) if clk else None,
+               "c2_effective_clock_ghz_bit_plane_kernel": round(clk0, 3) if clk0 else None},
               open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
 for c in stats:
