@@ -181,8 +181,13 @@ typedef struct phmm_stage_params { /* the constants of phmm_read_prep (no per-re
 int phmm_stage_create(phmm_context *ctx, const phmm_stage_caps *caps, phmm_stage **out);
 void phmm_stage_destroy(phmm_context *ctx, phmm_stage *st);
 int phmm_stage_get_view(const phmm_stage *st, phmm_stage_view *view, phmm_stage_caps *caps /* nullable */);
-/* asynchronous: validates and bins the first n_regions / n_reads / n_haps entries of the stage and enqueues set-up, sweep and
- * fp64 re-run on the context's stream.  The stage must not be written until phmm_stage_wait has returned. */
+/* asynchronous: validates and bins the first n_regions / n_reads / n_haps entries of the stage and enqueues set-up and the fp32 sweep
+ * on the context's stream.  The stage must not be written until phmm_stage_wait has returned.
+ * phmm_stage_wait waits for that, and -- only when a pair underflowed fp32 (round 4) -- launches the fp64 re-run of those pairs on `ctx`
+ * and waits for it: it is a call that launches work, not a pure wait.  So: `ctx` must be the context the stage was submitted on (the
+ * re-run uses that context's tables and streams), and calls that launch work on ONE context -- phmm_stage_submit, phmm_stage_wait,
+ * phmm_sweep, phmm_compute* -- must be serialised by the caller (one thread per context, as the in-tree adapter's dispatchers do;
+ * different contexts are independent). */
 int phmm_stage_submit(phmm_context *ctx, phmm_stage *st, uint32_t n_regions, uint32_t n_reads, uint32_t n_haps,
                       const phmm_stage_params *params);
 int phmm_stage_wait(phmm_context *ctx, phmm_stage *st, phmm_stats *stats /* nullable; n_rescued is not counted here */);

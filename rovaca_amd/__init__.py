@@ -32,6 +32,7 @@ def kernel_source_id():
     (tools/summarize_profiles.py); bench.py and the tests refuse counters taken from other sources, other flags or another build."""
     return _source_id(("pairhmm_kernels.hip", "pairhmm_systolic.h", "pairhmm_systolic_sweep.inc", "pairhmm_systolic_ugo_sweep.inc",
                        "pairhmm_kernels_ragged.hip", "pairhmm_kernels_tab.hip", "pairhmm_kernels_ragged_tab.hip", "pairhmm_systolic_tab.h",
+                       "pairhmm_systolic_tab_round.inc",
                        "pairhmm_device.h"))
 
 

@@ -197,12 +197,29 @@ void phmm_destroy(phmm_context *c)
 // GPU_MAX_HW_QUEUES hardware queues -- sixteen streams made at start-up by the adapter's four contexts, on top of the caller's own, meant
 // that two dispatchers' main streams could end up sharing a queue (whether they did depended on which thread created its streams first:
 // the synchronous seam measured 2 200 or 2 950 GCUPS from one run of bench.py to the next, round 4).
+// Not thread-safe: the caller serialises the calls that launch work on one context (include/pairhmm_hip.h).  All or nothing: the
+// streams and events are made into locals and published together, so a failure half way leaves the context without side streams
+// (and the next call tries again) instead of with a first stream that says "made" and null ones behind it.
 int ensure_side_streams(phmm_context *c)
 {
     if (c->cpu || c->side[0]) return PHMM_OK;
+    hipStream_t side[phmm_context::kSideStreams] = {};
+    hipEvent_t join[phmm_context::kSideStreams] = {};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < phmm_context::kSideStreams && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&join[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        for (int i = 0; i < phmm_context::kSideStreams; ++i) {
+            if (join[i]) (void)hipEventDestroy(join[i]);
+            if (side[i]) (void)hipStreamDestroy(side[i]);
+        }
+        return fail(PHMM_E_HIP, "side streams: %s", hipGetErrorString(e));
+    }
     for (int i = 0; i < phmm_context::kSideStreams; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming));
+        c->join[i] = join[i];
+        c->side[i] = side[i];
     }
     return PHMM_OK;
 }
@@ -379,9 +396,8 @@ int upload_prepare(phmm_context *c, const phmm_batch *b, phmm_resident *rb, cons
     // ---- pair list (materialise the cross product) and length binning: pairhmm_binning.cpp ----
     uint64_t cells = 0;
     {
-        harvest_history(c, rb);  // (the batch this slot held before: what its last pass saw goes into the context's history)
-        for (int qi = 0; qi < kQueues; ++qi) rb->f64_share_known[qi] = rb->queue_f64_first[qi] = false;  // a new batch: the context's history decides its first pass
-        rb->hist_pending = false;
+        // (what the batch this slot held before observed on its long pairs goes into the context's history in upload_enqueue -- the
+        // half that runs on the one enqueuing thread: this half runs on several prepare workers at once and must not write the context)
         rb->ragged = ragged_launches_for(ug);  // the classes share launches: no need for small ones to ride along at more rows per lane
         const int rc = phmm_detail::bin_pairs(b, cross, n_pairs, opt.read_bias, opt.hap_bias, pr, ph, order, bin_scratch, rb->bins, &cells,
                                               !rb->ragged);
@@ -421,6 +437,11 @@ int upload_enqueue(phmm_context *c, phmm_resident *rb, const UploadOpts &opt)
     const phmm_read_prep *prep = pl.has_prep ? &pl.prep : nullptr;
     const uint32_t n_reads = rb->n_reads, n_haps = rb->n_haps;
     hipStream_t st = opt.stream ? opt.stream : c->stream;
+    // the batch this slot held before: what its last pass saw goes into the context's history (fp64 first, pairhmm_sweep.cpp); the
+    // new batch starts from the context's history
+    harvest_history(c, rb);
+    for (int qi = 0; qi < kQueues; ++qi) rb->f64_share_known[qi] = rb->queue_f64_first[qi] = false;
+    rb->hist_pending = false;
     HIP_TRY(rb->blob.alloc(total));
     // ---- upload ----
     if (opt.setup_stream && opt.setup_stream != st) {

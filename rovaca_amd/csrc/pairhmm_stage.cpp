@@ -33,6 +33,7 @@ struct phmm_stage
     uint64_t n_pairs = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool in_flight = false;
+    const phmm_context *submitted_on = nullptr;  // the context of the submission in flight: phmm_stage_wait re-runs fp64 on it
     bool rescue_deferred = false;              // the submission's fp64 re-run is phmm_stage_wait's to launch, if a sum underflowed
     bool valid = false;                        // the last submission succeeded: the results and pair_first describe it
     phmm_stage_params params{};
@@ -385,6 +386,7 @@ int phmm_stage_submit(phmm_context *c, phmm_stage *st, uint32_t n_regions, uint3
         return rc;
     }
     st->in_flight = true;
+    st->submitted_on = c;
     st->valid = true;
     return PHMM_OK;
 }
@@ -394,6 +396,8 @@ int phmm_stage_wait(phmm_context *c, phmm_stage *st, phmm_stats *stats)
     if (!c || !st) return fail(PHMM_E_INVALID, "phmm_stage_wait: null argument");
     double ms = 0.0;
     if (!c->cpu && st->in_flight) {
+        if (st->submitted_on != c)  // (the fp64 re-run below would take the other context's tables and streams)
+            return fail(PHMM_E_INVALID, "phmm_stage_wait: the stage was submitted on another context");
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipEventSynchronize(st->ev1));
         if (st->rescue_deferred) {

@@ -556,7 +556,9 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
     // what this pass observed on its striped ranges, for the next one's choice of order (sweep_fp32, "fp64 first"): the counters come
     // back behind the pass, nobody waits for them
     bool observe = false;
-    for (int qi = 1; qi <= 4; ++qi) observe = observe || (rb->queue_sparse[qi] && q[qi].cap && !rb->out32_host);
+    // (not from a chunk slot of the one-shot pipeline: its passes always run fp32 first and its collector thread is not the one that
+    // reads the history)
+    for (int qi = 1; qi <= 4; ++qi) observe = observe || (rb->queue_sparse[qi] && q[qi].cap && !rb->out32_host && !rb->fp32_first_only);
     if (observe) {
         HIP_TRY(rb->hist_host.ensure(kQueues * sizeof(uint32_t)));
         if (!rb->hist_ready) HIP_TRY(hipEventCreateWithFlags(&rb->hist_ready, hipEventDisableTiming));

@@ -197,166 +197,43 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
     // the entry of this lane's column at step t is hp[t]: entry 16 + d + (t - lane) - 1
     const uint16_t *hp = reinterpret_cast<const uint16_t *>(hapl) + (15u + d - lane);
 
+    // The rounds.  A workgroup sweeps once unless it has more reads than table slots.  Two forms of the same text
+    // (pairhmm_systolic_tab_round.inc): the first round as straight-line code and the later ones as a loop of their own, or ONE loop
+    // over all rounds.  As one loop, what a round derives from `pad`, the read's offset and the pair id (each row's initial Y, the
+    // result's address) is hoisted out of the loop and stays live across the sweep, K + 10 registers: from 13 rows per lane on every
+    // lane then spills on its way into the sweep -- 0.3-0.9 GB of scratch stores per launch (WRITE_SIZE), more than the algorithmic
+    // bytes -- so those classes take the straight-line form, although the loop form runs 2-5 % faster even so (the stores are 5 % of
+    // the HBM's time).  (Making the three values opaque per iteration with an empty asm cured the hoisting too and cost the sweep
+    // 15 %.)  Below 13 rows nothing spills either way and the choice is by measurement, `tools/bench_sweep.py` on one box, GCUPS as
+    // loop / straight-line: one gap-open quality, reads of 60, 100, 125, 150, 170, 190 bases (K = 4, 7, 8, 10, 11, 12): 5 017 / 5 021,
+    // 5 777 / 5 804, 6 434 / 6 883, 7 047 / 6 003, 7 427 / 7 056, 7 656 / 7 721; per-base gap-opens: 4 511 / 4 886, 5 149 / 5 328,
+    // 5 767 / 5 974, 5 684 / 6 451, 6 338 / 6 579, 6 818 / 6 694 -- at instruction streams that differ by two moves per couple of steps
+    // and by which registers the allocator picked ("Register numbers matter": SQ_INSTS_VALU equal, SQ_WAIT_INST_ANY 7.9e9
+    // against 6.1e9).  So: the loop form for 10 and 11 rows per lane with one gap-open quality, the straight-line form everywhere else.
+    // -DPHMM_TAB_LOOP_FORM_ALL / _NONE: tuning (tools/build_tab_variant.sh).
+#if defined(PHMM_TAB_LOOP_FORM_ALL)
+    constexpr bool kOneLoop = true;
+#elif defined(PHMM_TAB_LOOP_FORM_NONE)
+    constexpr bool kOneLoop = false;
+#else
+    constexpr bool kOneLoop = UGO && (K == 10 || K == 11);
+#endif
+    if constexpr (!kOneLoop) {
+        {
+            const uint32_t base = 0;
+#include "pairhmm_systolic_tab_round.inc"
+        }
 #pragma unroll 1
-    for (uint32_t base = 0; base < n_tables; base += n_slots) {
-        const bool act = valid && slot >= base && slot - base < n_slots;
-        const uint32_t sl = act ? slot - base : 0u;
-        uint8_t *quads = lds_raw + sl * (Q * kTabQuadStride) + lane * 16u;
-        uint8_t *tails = lds_raw + tail_at + (TAIL == 2 ? (sl >> 1) * kTabQuadStride + (sl & 1u) * 128u + lane * 8u : (sl >> 2) * kTabQuadStride + (sl & 3u) * 64u + lane * 4u);
-        if (base) __syncthreads();  // the round before has read its tables
-        if (act && leader) {
-            // The read's table, four rows at a time (few registers live: this runs with the sweep's per-row constants already loaded).
-            // Symbol code s (ASCII bits 1-2: A 0, C 1, T 2, G 3) -> read class (A 0, C 1, G 2, T 3); a read N matches all; the fifth
-            // symbol (not a column of the haplotype) and the boundary replicas are 0.
-            auto row_entry = [&](int k, T &hi, T &lo, uint32_t &cls) {
-                const int row = static_cast<int>(lane) * K + k - pad;
-                cls = 5, hi = 0, lo = 0;
-                if (k < K && row >= 0) {
-                    const uint32_t at = roff + static_cast<uint32_t>(row);
-                    const T dist = ph2pr[a.read_qual[at] & 127u];
-                    hi = static_cast<T>(1.0) - dist;
-                    lo = Num<T>::div3(dist);
-                    cls = read_class(a.read_bases[at]);
-                }
-            };
-            auto pick = [](T hi, T lo, uint32_t cls, uint32_t s) -> T {
-                if (s == 4u) return 0;
-                const uint32_t c = s == 2u ? 3u : s == 3u ? 2u : s;
-                return (cls == c || cls == 4u) ? hi : lo;
-            };
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                T hi[4], lo[4];
-                uint32_t cls[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) row_entry(4 * q + j, hi[j], lo[j], cls[j]);
-#pragma unroll
-                for (uint32_t s = 0; s < kTabSyms; ++s) {
-                    float4 v;
-                    v.x = pick(hi[0], lo[0], cls[0], s), v.y = pick(hi[1], lo[1], cls[1], s), v.z = pick(hi[2], lo[2], cls[2], s),
-                    v.w = pick(hi[3], lo[3], cls[3], s);
-                    *reinterpret_cast<float4 *>(quads + q * kTabQuadStride + s * kTabSymStride) = v;
-                }
-            }
-            if constexpr (TAIL != 0) {
-                T hi[2], lo[2];
-                uint32_t cls[2];
-                row_entry(4 * Q, hi[0], lo[0], cls[0]);
-                row_entry(4 * Q + 1, hi[1], lo[1], cls[1]);  // (TAIL == 1: row K, which row_entry leaves at 0)
-#pragma unroll
-                for (uint32_t s = 0; s < kTabSyms; ++s) {
-                    if constexpr (TAIL == 2) {
-                        float2 v;
-                        v.x = pick(hi[0], lo[0], cls[0], s), v.y = pick(hi[1], lo[1], cls[1], s);
-                        *reinterpret_cast<float2 *>(tails + s * kTabSymStride) = v;
-                    }
-                    else
-                        *reinterpret_cast<float *>(tails + s * kTabSymStride) = pick(hi[0], lo[0], cls[0], s);
-                }
-            }
+        for (uint32_t base = n_slots; base < n_tables; base += n_slots) {
+            __syncthreads();  // the round before has read its tables
+#include "pairhmm_systolic_tab_round.inc"
         }
-        __syncthreads();  // tables (and, the first time, the haplotype entries) are read by other lanes than wrote them
-
-        // ---- the sweep ----
-        const uint32_t Tg = act ? H + (G - 1) : 0;  // last step of this group
-        uint32_t Tmax = Tg;
-        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 16));
-        Tmax = max(Tmax, (uint32_t)__shfl_xor((int)Tmax, 32));
-        Tmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Tmax);
-        if (Tmax == 0) continue;  // none of the wave's four pairs is in this round
-
-        T M[K], X[K], Y[K];
-        T PM[UGO && K > 1 ? K - 1 : 1];  // UGO: M[k] * p_mx of the anti-diagonal before, computed in pass 2 and used again in pass 1
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            M[k] = 0;
-            X[k] = 0;
-            Y[k] = static_cast<int>(lane) * K + k < pad ? init_y : static_cast<T>(0);
-        }
-        if constexpr (UGO) {
-#pragma unroll
-            for (int k = 0; k + 1 < K; ++k) PM[k] = 0;
-        }
-        T aM = 0, aX = 0, aY = y_col0, bM = 0, bX = 0, bY = y_col0;
-        T sumM = 0, sumX = 0;
-        T pr[K];  // the priors of the step in hand; pass 1 uses them, and the next step's are fetched into the same registers behind it
-        auto fetch = [&](uint32_t so) {
-            const uint8_t *tq = quads + so;
-#pragma unroll
-            for (int q = Q - 1; q >= 0; --q) {  // (pass 1 walks bottom-up: the last rows are needed first)
-                const float4 v = *reinterpret_cast<const float4 *>(tq + q * kTabQuadStride);
-                pr[4 * q] = v.x;
-                if (4 * q + 1 < K) pr[4 * q + 1] = v.y;
-                if (4 * q + 2 < K) pr[4 * q + 2] = v.z;
-                if (4 * q + 3 < K) pr[4 * q + 3] = v.w;
-            }
-            if constexpr (TAIL == 2) {
-                const float2 v = *reinterpret_cast<const float2 *>(tails + so);
-                pr[4 * Q] = v.x;
-                pr[4 * Q + 1] = v.y;
-            }
-            if constexpr (TAIL == 1) pr[4 * Q] = *reinterpret_cast<const float *>(tails + so);
-        };
-        // One anti-diagonal.  (dM, dX, dY): row above slot 0 at the previous column; (uM0, uX0, uY0): receives it at this column.  The
-        // arithmetic is the bit-plane sweeps', statement for statement.  Pass 1 (bottom row first, in place) is the only user of the
-        // priors; the table reads of the next step are issued right behind it and land while pass 2 (top row first: the insertion state
-        // chains down through the new M and X) runs.
-        uint32_t so_next;  // the haplotype entry of step t + 1
-        auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
-            uM0 = dpp_shr1<G>(uM0, M[K - 1]);
-            uX0 = dpp_shr1<G>(uX0, X[K - 1]);
-            uY0 = dpp_shr1<G>(uY0, Y[K - 1]);
-#pragma unroll
-            for (int k = K - 1; k >= 0; --k) {
-                if constexpr (UGO)
-                    Y[k] = Num<T>::fma_(Y[k], p_yy[k], k == K - 1 ? M[K - 1] * u_mx : PM[k < K - 1 ? k : 0]);
-                else
-                    Y[k] = Num<T>::fma_(Y[k], p_yy[k], M[k] * f_mx(k));
-                const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
-                T tt = gM * f_mm(k);
-                tt = Num<T>::fma_(gX, p_gapm, tt);
-                tt = Num<T>::fma_(gY, p_gapm, tt);
-                M[k] = tt * pr[k];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#ifdef PHMM_TAB_DEBUG_WAIT_BEFORE_FETCH
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_s_nop(4);
-#endif
-            fetch(so_next);
-            so_next = hp[t + 2];
-#ifdef PHMM_TAB_DEBUG_WAIT_AFTER_FETCH
-            __builtin_amdgcn_s_waitcnt(0);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            T uM = uM0, uX = uX0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const T prod = uM * f_mx(k);
-                X[k] = Num<T>::fma_(uX, p_xx, prod);
-                if constexpr (UGO)
-                    if (k >= 1) PM[k - 1] = prod;
-                uM = M[k];
-                uX = X[k];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            sumM = sumM + M[K - 1];  // rovaca/avx_512_float.cc:166-171 (only lane 15 is read back)
-            sumX = sumX + X[K - 1];
-        };
-        // Steps go in (odd, even) couples so that the two row-above sets swap roles without a move.  No fill, no drain, no predicate:
-        // what a lane computes outside its haplotype's columns changes nothing (the zero symbol, above); the loop may run one step past
-        // the wave's last.
-        fetch(hp[1]);
-        so_next = hp[2];
-        for (uint32_t t = 1; t <= Tmax; t += 2) {
-            step(t, aM, aX, aY, bM, bX, bY);
-            step(t + 1, bM, bX, bY, aM, aX, aY);
-        }
-        if (act && lane == G - 1) {
-            const T res = sumM + sumX;
-            reinterpret_cast<T *>(a.out_raw)[pair] = res;
-            if (rescue_list && res < static_cast<T>(1e-28f))  // pairhmm_internal.cpp:578: queue for fp64
-                rescue_list[atomicAdd(rescue_count, 1u)] = pair;
+    }
+    else {
+#pragma unroll 1
+        for (uint32_t base = 0; base < n_tables; base += n_slots) {
+            if (base) __syncthreads();  // the round before has read its tables
+#include "pairhmm_systolic_tab_round.inc"
         }
     }
 }

@@ -252,6 +252,38 @@ def test_config5_corner_10k_by_12k(engine, monkeypatch):
     assert np.array_equal(fl10, l10, equal_nan=True) and int(fst.n_rescued) == int(st.n_rescued) and (fraw < np.float32(1e-28)).all()
 
 
+def test_config5_shape_under_the_library_default_order_of_passes(engine, monkeypatch):
+    # No hook at all (the suite otherwise pins PHMM_F64_FIRST=0): a resident batch of long pairs that all underflow fp32 is swept fp32
+    # first on its first pass and fp64 first from the second pass on (pairhmm_sweep.cpp, "fp64 first").  The log10 values and the rescue
+    # decisions must be the same on every pass and equal to the oracle's; the fp32 sums of the later passes are 0 where the library
+    # proved the underflow (include/pairhmm_hip.h).
+    monkeypatch.delenv("PHMM_F64_FIRST", raising=False)
+    rng = np.random.default_rng(56)
+    reads, haps = [], []
+    for R, H in ((2100, 2600), (2500, 3000), (2300, 4000)):
+        rd, hp = _long_pair(rng, R, H)
+        reads.append(rd)
+        haps.append(hp)
+    b = Batch.from_lists(reads, haps, [(0, 0), (1, 1), (2, 2), (0, 2), (1, 0)])
+    oraw, ol10, oresc = oracle.batch(b, n_threads=5)
+    assert oresc.all()
+    eng2 = capi.Engine(0)  # a fresh context: no history
+    rb = eng2.upload(b)
+    passes = []
+    for _ in range(3):
+        rb.sweep()
+        passes.append(rb.download())
+    rb.release()
+    eng2.close()
+    raw1, l10_1, st1 = passes[0]
+    assert np.array_equal(raw1.view(np.uint32), oraw.view(np.uint32))  # first pass: the reference's order, every fp32 sum computed
+    for raw, l10, st in passes:
+        fin = np.isfinite(ol10)
+        assert np.array_equal(np.isfinite(l10), fin) and np.abs(l10[fin] - ol10[fin]).max() <= 1e-9
+        assert np.array_equal(l10, l10_1, equal_nan=True) and int(st.n_rescued) == int(oresc.sum())
+        assert ((raw.view(np.uint32) == oraw.view(np.uint32)) | (raw == 0)).all()
+
+
 def test_config5_full_size_properties(engine, monkeypatch):
     # all 1 000 pairs of config 5 (the oracle would need hours): every result finite or -inf and never NaN, the same bits in
     # any pair order, and the same bits with the zero-superstep shortcut switched off
