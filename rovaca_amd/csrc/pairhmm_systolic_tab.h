@@ -209,14 +209,16 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
     // 5 777 / 5 804, 6 434 / 6 883, 7 047 / 6 003, 7 427 / 7 056, 7 656 / 7 721; per-base gap-opens: 4 511 / 4 886, 5 149 / 5 328,
     // 5 767 / 5 974, 5 684 / 6 451, 6 338 / 6 579, 6 818 / 6 694 -- at instruction streams that differ by two moves per couple of steps
     // and by which registers the allocator picked ("Register numbers matter": SQ_INSTS_VALU equal, SQ_WAIT_INST_ANY 7.9e9
-    // against 6.1e9).  So: the loop form for 10 and 11 rows per lane with one gap-open quality, the straight-line form everywhere else.
+    // against 6.1e9).  (A second run, K = 2, 3, 5, 6, 9: 3 938 / 3 986, 4 822 / 4 770, 5 891 / 5 491, 6 319 / 6 259, 6 772 / 6 711; per-base
+    // 3 773 / 3 885, 4 495 / 4 451, 5 317 / 5 222, 5 509 / 5 472, 6 358 / 6 216.)  So: the loop form for 5, 6, 9, 10 and 11 rows per lane
+    // with one gap-open quality, the straight-line form everywhere else.
     // -DPHMM_TAB_LOOP_FORM_ALL / _NONE: tuning (tools/build_tab_variant.sh).
 #if defined(PHMM_TAB_LOOP_FORM_ALL)
     constexpr bool kOneLoop = true;
 #elif defined(PHMM_TAB_LOOP_FORM_NONE)
     constexpr bool kOneLoop = false;
 #else
-    constexpr bool kOneLoop = UGO && (K == 10 || K == 11);
+    constexpr bool kOneLoop = UGO && (K == 5 || K == 6 || K == 9 || K == 10 || K == 11);
 #endif
     if constexpr (!kOneLoop) {
         {
