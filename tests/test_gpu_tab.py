@@ -147,3 +147,15 @@ def test_resident_batch_and_sample_of_config2(engine, monkeypatch):
     sample = np.random.default_rng(1).choice(b.n_pairs, 2000, replace=False)
     oraw, _, _ = oracle.batch(b.subset(sample), n_threads=8)
     assert np.array_equal(_bits(raw[sample]), _bits(oraw))
+
+
+def test_long_haplotypes_leave_no_room_for_tables_and_take_the_bit_plane_kernels(engine, monkeypatch):
+    # 16 haplotypes of 1 500-2 500 columns are 50-80 KB of entries: no table fits next to them at four workgroups per CU, so these
+    # classes keep the bit-plane kernels (pairhmm_sweep.cpp: tab_slots_of); shorter haplotypes in the same batch take the table sweep
+    monkeypatch.setenv("PHMM_FORCE_LANES", "16")
+    parts = [synth.make_batch(seed=41, n_regions=6, reads=20, haps=6, read_len=(60, 150), hap_len=(1500, 2500)),
+             synth.make_batch(seed=42, n_regions=6, reads=20, haps=6, read_len=(60, 150), hap_len=(200, 400))]
+    for b in parts + [Batch.concat(parts)]:
+        raw, l10, _ = _both_ways(engine, b, monkeypatch)
+        _against_oracle(b, raw, l10)
+
