@@ -103,6 +103,7 @@ struct KernelArgs
     uint32_t tab_max_hap;
     uint32_t tab_slots;  // tables per workgroup (LDS)
     uint32_t tab_max_read;  // longest read of the launch (read by the eight-lane experiment only: -DPHMM_EXPERIMENT_TAB8)
+    uint32_t band_tab;      // the fp64 band kernel may take its table form (hap_bases / hap_off / tab_max_hap set)
 };
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;
 constexpr int kTimelineStripes = 64, kTimelineWords = 8;
@@ -174,6 +175,14 @@ inline size_t team_lds_bytes(uint32_t plane_words_per_group, int waves_per_team,
     // planes of the team's pairs, one carry ring per (wave, group), and the waves' progress records (2 rounds x waves x 8 words)
     return groups * (size_t)plane_words_per_group * sizeof(uint32_t) + (size_t)waves_per_team * groups * 3u * 64u * value_bytes +
            2u * (size_t)waves_per_team * 8u * sizeof(uint32_t);
+}
+// the band kernel's table form (fp64, 4 rows per lane, 64 lanes per pair): haplotype entries (16 bits per column, 64 in front, 72
+// behind, whole 64-entry rounds) and one 12 KB table per wave in front of the rings
+constexpr uint32_t kBandTabBytes = 2u * 6u * 1024u;
+inline __host__ __device__ uint32_t band_tab_hap_bytes(uint32_t max_hap) { return 2u * ((64u + max_hap + 72u + 63u) & ~63u); }
+inline __host__ __device__ uint32_t band_tab_front_bytes(uint32_t max_hap, int waves_per_team)
+{
+    return band_tab_hap_bytes(max_hap) + (uint32_t)waves_per_team * kBandTabBytes;
 }
 inline size_t team_carry_values(uint32_t teams, int waves_per_team, uint32_t carry_stride, int lanes_per_pair)
 {

@@ -529,9 +529,17 @@ template <int G> __device__ __forceinline__ uint32_t team_last_block(uint32_t l)
 #ifndef PHMM_BAND_PREFETCH_BLOCKS
 #define PHMM_BAND_PREFETCH_BLOCKS 2  // 1: the shorter hand-over lag tried in round 4 (tools/build_variant.sh for the A/B): no gain, see kPrefetch
 #endif
-template <typename T, int K, bool UG, int WP, int G>
+// TABP (round 5; fp64, 4 rows per lane, one pair per wave): the prior is looked up in a table in LDS instead of selected by a match bit
+// -- the single-pass table sweep's idea (pairhmm_systolic_tab.h) where it pays most: an fp64 select is a bit pop and TWO 32-bit
+// selects, three VALU instructions per cell beside nine fp64 ones.  Each wave keeps the table of the stripe it sweeps (its own 256
+// rows: a lane writes and reads only its own four rows' entries, so no barrier is involved): [half: rows 0-1 / 2-3][symbol][lane] x 16
+// bytes, SIX symbols -- A, C, T, G (ASCII bits 1-2), N (matches every base and N), anything else (matches nothing:
+// pairhmm_internal.cpp:27-41) -- so haplotypes with N need no other path here.  The haplotype is staged once per pair as one 16-bit
+// entry per column (symbol x 1024), 64 entries in front for the columns a lane "sees" before its first.
+template <typename T, int K, bool UG, int WP, int G, bool TABP = false>
 __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 : PHMM_TEAM_WAVES_F64) pairhmm_band_kernel(KernelArgs a, T *__restrict__ carry, uint32_t carry_stride)
 {
+    static_assert(!TABP || (sizeof(T) == 8 && K == 4 && G == 64), "the table form is the fp64 band kernel's");
     extern __shared__ uint32_t lds[];
     constexpr int S = G * K;
     constexpr uint32_t kGroups = 64 / G;  // pairs per wave
@@ -553,8 +561,11 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
     const T *__restrict__ ph2pr = reinterpret_cast<const T *>(a.ph2pr);
     const T *__restrict__ mmtab = reinterpret_cast<const T *>(a.mm_table);
     // LDS: [kGroups][planes] shared by the team, then [WP waves][kGroups][3 values][kRing] carry ring
-    const uint32_t plane_words = a.lds_words_per_group;
+    // (table form: [haplotype entries][WP tables] instead of the planes, sized by band_tab_front_bytes)
+    const uint32_t plane_words = TABP ? band_tab_front_bytes(a.tab_max_hap, WP) / 4u : a.lds_words_per_group;
     uint32_t *pl = lds + grp * plane_words;
+    uint8_t *const tab_hap = reinterpret_cast<uint8_t *>(lds);
+    uint8_t *const tab_mine = reinterpret_cast<uint8_t *>(lds) + band_tab_hap_bytes(a.tab_max_hap) + wave * kBandTabBytes + (threadIdx.x & 63u) * 16u;
     T *ring = reinterpret_cast<T *>(lds + kGroups * plane_words) + (static_cast<size_t>(wave) * kGroups + grp) * 3u * kRing;
     // progress records of the team's waves: [round parity][wave][stripe + 1, supersteps done, first carry block with output, last
     // carry block with output (once the stripe is finished), superstep the sweep began at, "a wait timed out somewhere up the
@@ -610,10 +621,37 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
         const uint32_t roff = a.read_off[r];
         const uint32_t W = planes_words(H);
         __syncthreads();  // the previous quad's planes are no longer read
-        {
+        if constexpr (TABP) {
+            // entry 64 + d + (j - 1) for column j (d = the haplotype's offset in its dword); everything that is not a column: symbol 5
+            const uint32_t hoff = a.hap_off[h];
+            const uint32_t d = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(a.hap_bases) + hoff) & 3u);
+            const uint8_t *__restrict__ src = a.hap_bases + hoff - d;
+            constexpr uint32_t kNone = 5u * 1024u;
+            const uint32_t n_dwords = band_tab_hap_bytes(a.tab_max_hap) / 8u - 16u;  // entries / 4 behind the 64 in front
+            for (uint32_t i = threadIdx.x; i < 16u; i += 64u * WP) reinterpret_cast<uint2 *>(tab_hap)[i] = uint2{kNone | (kNone << 16), kNone | (kNone << 16)};
+            for (uint32_t i = threadIdx.x; i < n_dwords; i += 64u * WP) {
+                const uint32_t b0 = 4u * i;
+                uint32_t e[4] = {kNone, kNone, kNone, kNone};
+                if (b0 + 3u >= d && b0 < d + H) {
+                    const uint32_t w = *reinterpret_cast<const uint32_t *>(src + b0);
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        const uint32_t b = (w >> (8u * q)) & 255u;
+                        const uint32_t c = (b >> 1) & 3u;  // A 0, C 1, T 2, G 3
+                        const uint32_t sym = b == ((0x47544341u >> (8u * c)) & 255u) ? c : b == 'N' ? 4u : 5u;
+                        if (b0 + q >= d && b0 + q < d + H) e[q] = sym * 1024u;
+                    }
+                }
+                reinterpret_cast<uint2 *>(tab_hap)[16u + i] = uint2{e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+            }
+        }
+        else {
             const uint32_t *src = a.planes + a.plane_off[h];
             for (uint32_t i = lane + G * wave; i < kPlanes * W; i += G * WP) pl[i] = src[i];
         }
+        const uint32_t tab_d = TABP ? static_cast<uint32_t>((reinterpret_cast<uintptr_t>(a.hap_bases) + a.hap_off[h]) & 3u) : 0u;
+        // the entry of this lane's column at step t is tab_hp[t]: entry 64 + d + (t - lane) - 1
+        const uint16_t *const tab_hp = reinterpret_cast<const uint16_t *>(tab_hap) + (63u + tab_d - lane);
         if (WP > 1 && threadIdx.x < 2u * WP * 8u) team_rec[threadIdx.x] = 0;  // no wave has begun any stripe of these pairs
         const T init_y = Num<T>::init_const() / static_cast<T>(H);
         const uint32_t n_stripes = valid ? (R + S - 1) / S : 0;
@@ -646,6 +684,9 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
         Rows<T, K, UG> P;
         T M[K], X[K], Y[K];
         uint32_t mask[K];
+        T pr[TABP ? K : 1];     // table form: the priors of the step in hand ...
+        uint32_t so_next = 0;   // ... the haplotype entry of the next step ...
+        uint32_t tab_at = 0;    // ... and which step that is (0: none -- a new stripe's table, or supersteps were skipped)
         uint32_t cls_lo = 0, cls_hi = 0;
         T aM = 0, aX = 0, aY = 0, bM = 0, bX = 0, bY = 0;
         T preM[2], preX[2], preY[2];
@@ -746,6 +787,7 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             last = stripe + 1 == n_stripes;
             const bool live = valid && in_play;
             Tg = live ? Tpair : 0;
+            tab_at = 0;  // (table form: this stripe's table is about to be written)
             cls_lo = 0;
             cls_hi = 0;
             if (UG) {
@@ -797,6 +839,16 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                     cls_lo |= cls << (3 * k);
                 else
                     cls_hi |= cls << (3 * (k - 10));
+                if constexpr (TABP) {
+                    // this row's six priors: one-hot semantics (pairhmm_internal.cpp:27-41) -- symbol codes A 0, C 1, T 2, G 3, N 4, other 5
+                    // against the read's class A 0, C 1, G 2, T 3, N 4, other 5
+#pragma unroll
+                    for (uint32_t sy = 0; sy < 6; ++sy) {
+                        const uint32_t hc = sy == 2u ? 3u : sy == 3u ? 2u : sy;  // the symbol as a read class
+                        const bool m = cls != 5u && sy != 5u && (cls == 4u || sy == 4u || cls == hc);
+                        reinterpret_cast<T *>(tab_mine + (k >> 1) * (kBandTabBytes / 2) + sy * 1024u)[k & 1] = m ? P.hi[k] : P.lo[k];
+                    }
+                }
             }
             // column 0 of the row above slot 0: init for the boundary row and its replicas (stripe 0 only), else 0
             const T y_col0 = (first && static_cast<int>(lane) * K <= pad) ? init_y : static_cast<T>(0);
@@ -828,17 +880,47 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
             curX = nxtX;
             curY = nxtY;
         };
-        auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0, auto is_last) {
+        auto tab_fetch = [&](uint32_t so) {
+            if constexpr (TABP) {
+#pragma unroll
+                for (int hf = 0; hf < K / 2; ++hf) {
+                    const double2 v = *reinterpret_cast<const double2 *>(tab_mine + hf * (kBandTabBytes / 2) + so);
+                    pr[2 * hf] = v.x;
+                    pr[2 * hf + 1] = v.y;
+                }
+            }
+        };
+        auto tab_prime = [&](uint32_t t) {  // before the first step t of a superstep that is swept
+            if constexpr (TABP) {
+                if (tab_at == t) return;  // the last step of the superstep before fetched them already
+                tab_fetch(tab_hp[t]);
+                so_next = tab_hp[t + 1];
+                tab_at = t;
+            }
+        };
+        auto tab_next = [&](uint32_t t) {  // behind pass 1 of step t: the priors of step t + 1 into the same registers
+            if constexpr (TABP) {
+                tab_fetch(so_next);
+                so_next = tab_hp[t + 2];
+                tab_at = t + 1;
+            }
+        };
+        auto step_a = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0) {
             // lane 0 keeps `old` = the row above at column t (boundary row or carry); lanes 1..15 take lane-1's last row
             uM0 = dpp_shr1<G>(curM, M[K - 1]);
             uX0 = dpp_shr1<G>(curX, X[K - 1]);
             uY0 = dpp_shr1<G>(curY, Y[K - 1]);
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
-                uint32_t nm;
-                const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
-                mask[k] = nm;
-                const T prior = hit ? P.hi[k] : P.lo[k];
+                T prior;
+                if constexpr (TABP)
+                    prior = pr[k];
+                else {
+                    uint32_t nm;
+                    const bool hit = __builtin_uadd_overflow(mask[k], mask[k], &nm);
+                    mask[k] = nm;
+                    prior = hit ? P.hi[k] : P.lo[k];
+                }
                 Y[k] = Num<T>::fma_(Y[k], P.p_yy[k], M[k] * P.p_my(k));
                 const T gM = k ? M[k ? k - 1 : 0] : dM, gX = k ? X[k ? k - 1 : 0] : dX, gY = k ? Y[k ? k - 1 : 0] : dY;
                 T tt = gM * P.p_mm[k];
@@ -847,6 +929,8 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 M[k] = tt * prior;
                 if (PHMM_BAND_ROW_BARRIER) __builtin_amdgcn_sched_barrier(0);  // rows in program order: see the macro
             }
+        };
+        auto step_b = [&](uint32_t t, T &uM0, T &uX0, auto is_last) {
             T uM = uM0, uX = uX0;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -866,6 +950,11 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 };
                 *reinterpret_cast<V3 *>(wbase + (j * kGroups + grp) * 3u) = V3{M[K - 1], X[K - 1], Y[K - 1]};
             }
+        };
+        auto step = [&](uint32_t t, T &dM, T &dX, T &dY, T &uM0, T &uX0, T &uY0, auto is_last) {
+            step_a(t, dM, dX, dY, uM0, uX0, uY0);
+            tab_next(t);
+            step_b(t, uM0, uX0, is_last);
         };
         // 32 steps with every lane of the wave busy: no per-lane predicate, the two register sets swap roles without a move; `mid` runs
         // once, half way (the late park of the next carry block)
@@ -948,7 +1037,10 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                 curY = nxtY;
             }
             else {
-                masks_reload(t0);
+                if constexpr (TABP)
+                    tab_prime(t0);
+                else
+                    masks_reload(t0);
                 if (t0 > (uint32_t)(G - 1) && t0 + 31u <= Tmin) {
                     // steady state (t0 is odd).  Every group is live, so `last` is the same for the whole wave.
                     auto mid = [&]() {
@@ -967,7 +1059,23 @@ __global__ void __launch_bounds__(64 * WP, sizeof(T) == 4 ? PHMM_TEAM_WAVES_F32 
                             parked = true;
                         }
                         ring_fetch(t + 1);  // LDS latency hides behind this step's arithmetic
-                        if ((t > lane) && (t <= Tg)) {
+                        const bool lv = (t > lane) && (t <= Tg);
+                        if constexpr (TABP) {  // (the priors of the next step are fetched by every lane, live or not)
+                            if (lv) {
+                                if (t & 1u)
+                                    step_a(t, aM, aX, aY, bM, bX, bY);
+                                else
+                                    step_a(t, bM, bX, bY, aM, aX, aY);
+                            }
+                            tab_next(t);
+                            if (lv) {
+                                if (t & 1u)
+                                    step_b(t, bM, bX, last);
+                                else
+                                    step_b(t, aM, aX, last);
+                            }
+                        }
+                        else if (lv) {
                             if (t & 1u)
                                 step(t, aM, aX, aY, bM, bX, bY, last);
                             else
@@ -1211,8 +1319,23 @@ static hipError_t launch_team_one(const KernelArgs &a, void *carry, uint32_t car
     };
     if constexpr (WP == 1)
         return launch(pairhmm_team_kernel<T, K, UG, 1, G>);
-    else
+    else {
+        if constexpr (sizeof(T) == 8 && K == 4 && G == 64 && WP == 4) {
+            // the table form (round 5) when the launch asks for it and two teams still fit a CU with its LDS
+            const size_t tab_shmem = band_tab_front_bytes(a.tab_max_hap, WP) + team_lds_bytes(0, WP, sizeof(T), G);
+            if (a.band_tab && a.hap_bases && a.hap_off && tab_shmem <= 80u * 1024u) {
+                auto kern = pairhmm_band_kernel<T, K, UG, WP, G, true>;
+                if (tab_shmem > 64u * 1024u) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       static_cast<int>(tab_shmem));
+                    if (e != hipSuccess) return e;
+                }
+                hipLaunchKernelGGL(kern, dim3(teams), dim3(64 * WP), tab_shmem, s, a, static_cast<T *>(carry), carry_stride);
+                return hipGetLastError();
+            }
+        }
         return launch(pairhmm_band_kernel<T, K, UG, WP, G>);
+    }
 }
 
 // one instantiation per (type, rows per lane, waves per team): one wave per team is the lock-step team kernel at the stripe

@@ -485,6 +485,11 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
         }
         a.lds_words_per_group = (uint32_t)phmm::kPlanes * phmm::planes_words(L.max_hap);
         a.no_early_exit = phmm_hook("PHMM_NO_EARLY_EXIT") ? 1u : 0u;  // tests
+        // the fp64 band kernel's table form (round 5): needs the haplotypes' bases; PHMM_NO_BAND_TAB: A/B and test hook
+        a.hap_bases = rb->hap_bases.p;
+        a.hap_off = rb->hap_off.p;
+        a.tab_max_hap = L.max_hap;
+        a.band_tab = rb->hap_bases.p && rb->hap_off.p && !phmm_hook("PHMM_NO_BAND_TAB") ? 1u : 0u;
         a.ph2pr = c->ph2pr_f64.p;
         a.mm_table = c->mm_f64.p;
         a.out_raw = rb->out64_host ? static_cast<void *>(rb->out64_host) : static_cast<void *>(rb->raw64.p);
@@ -517,6 +522,7 @@ int sweep_rescue(phmm_context *c, phmm_resident *rb, const phmm_context::SweepLa
                 b.rescue_list = nullptr;
                 b.rescue_count = nullptr;
                 b.need32_above = 0.0;
+                b.band_tab = 0;
                 b.timeline = nullptr;
                 b.timeline_teams = 0;
                 b.lds_words_per_group = bin.lds_words_per_group;

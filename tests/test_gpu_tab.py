@@ -159,3 +159,47 @@ def test_long_haplotypes_leave_no_room_for_tables_and_take_the_bit_plane_kernels
         raw, l10, _ = _both_ways(engine, b, monkeypatch)
         _against_oracle(b, raw, l10)
 
+
+def _long_pair(rng, R, H, n_rate=0.0, other=False):
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, H)]
+    a0 = int(rng.integers(0, H - R + 1))
+    seq = hap[a0:a0 + R].copy()
+    bad = rng.random(R) < 0.12
+    seq[bad] = acgt[rng.integers(0, 4, int(bad.sum()))]
+    if n_rate:
+        hap = hap.copy()
+        hap[rng.random(H) < n_rate] = ord("N")
+        seq[rng.random(R) < n_rate] = ord("N")
+    if other:
+        hap[int(rng.integers(0, H))] = ord("x")
+        seq[int(rng.integers(0, R))] = ord("y")
+    q = rng.choice(np.array([8, 20, 30, 37], np.uint8), R)
+    g = np.full(R, 40, np.uint8)
+    return (seq, q, g, g, np.full(R, 10, np.uint8)), hap
+
+
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_fp64_band_kernel_table_form_is_the_plane_form(engine, order, monkeypatch):
+    # long pairs that underflow fp32: the fp64 band kernel (four waves per pair) in its table form -- six symbols, so N and other bytes
+    # in haplotype and read need no other path -- against the bit-plane form (PHMM_NO_BAND_TAB) and, for the smaller pairs, the oracle;
+    # both orders of passes (fp32 first: the kernel walks a rescue list; fp64 first: every pair)
+    monkeypatch.setenv("PHMM_F64_FIRST", order)
+    rng = np.random.default_rng(61)
+    reads, haps = [], []
+    for R, H, nr, oth in ((2100, 2600, 0.0, False), (2500, 3000, 0.01, False), (2300, 4100, 0.0, True), (3000, 3001, 0.02, True), (2050, 5000, 0.0, False)):
+        rd, hp = _long_pair(rng, R, H, nr, oth)
+        reads.append(rd)
+        haps.append(hp)
+    b = Batch.from_lists(reads, haps, [(0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (0, 2), (1, 0), (3, 1)])
+    raw, l10, st = engine.compute(b)
+    monkeypatch.setenv("PHMM_NO_BAND_TAB", "1")
+    raw0, l100, st0 = engine.compute(b)
+    monkeypatch.delenv("PHMM_NO_BAND_TAB")
+    assert np.array_equal(l10, l100, equal_nan=True) and int(st.n_rescued) == int(st0.n_rescued) > 0
+    assert np.array_equal(_bits(raw), _bits(raw0))
+    small = np.array([0, 1, 6])
+    oraw, ol10, oresc = oracle.batch(b.subset(small), n_threads=3)
+    fin = np.isfinite(ol10)
+    assert np.array_equal(np.isfinite(l10[small]), fin) and (not fin.any() or np.abs(l10[small][fin] - ol10[fin]).max() <= 1e-9)
+
