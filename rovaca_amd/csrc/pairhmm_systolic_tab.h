@@ -10,8 +10,9 @@
 // What differs is where `prior` comes from.  The bit-plane sweeps pop one match bit per cell into VCC and select (1 - e) or e/3 with
 // it: two VALU instructions per cell of the 9 (one gap-open quality) or 10 the cell costs, in kernels bound by VALU issue.  Here the
 // two go away.  prior[i][j] depends on the read row i (its base and quality) and on the haplotype SYMBOL at column j only, so a READ
-// gets a table  prior[row][symbol]  for the four symbols A, C, G, T in LDS -- 16 bytes per row, K x 256 bytes per read -- laid out so
-// that one `ds_read_b128` returns the priors of four consecutive rows of a lane for the symbol of its column:
+// gets a table  prior[row][symbol]  in LDS for the four symbols A, C, G, T and a fifth whose priors are all 0 (below) -- 20 bytes per
+// row slot, K x 320 bytes per read -- laid out so that one `ds_read_b128` returns the priors of four consecutive rows of a lane for the
+// symbol of its column:
 //
 //      quads:   slot * Q * 1280 + q * 1280 + symbol * 256 + lane * 16       (rows 4q .. 4q+3 of `lane`; five symbols, below)
 //      halves:  symbol * 256 + (slot & 1) * 128 + lane * 8  in block slot/2  (K mod 4 == 2: the last two rows; two tables interleave)
@@ -29,9 +30,14 @@
 // that jump between reads at every pair).
 //
 // The haplotype travels as one 16-bit entry per column (symbol * 256, ready to add) in LDS as well; a lane reads the entry of ITS
-// column each step (`ds_read_u16`), adds its table base (one or two `v_add_u32`) and issues the K / 4 table reads for the NEXT step
-// while it computes this one, so the LDS latency is covered by a whole step of arithmetic.  LDS instructions do not take VALU issue
+// column each step (`ds_read_u16`), adds its table base (one or two `v_add_u32`) and issues the K / 4 table reads of the NEXT step
+// right behind pass 1 -- the only user of the priors -- into the same registers, so that pass 2's 2 K instructions cover the LDS
+// latency and 16 rows per lane fit 128 registers (every class runs at four waves per SIMD).  LDS instructions do not take VALU issue
 // slots: per step and K = 10 the wave issues 71 arithmetic + 3 DPP + 2 sums + 2-3 address instructions instead of 101.
+//
+// No predicates: every haplotype entry that is NOT a column of the haplotype names the fifth symbol.  A lane that computes such a
+// column leaves the column-0 state of its rows as it is and adds 0 to both sums (see the staging code), so the sweep is one loop from
+// step 1 to the wave's last step -- no fill, no drain.
 //
 // Haplotypes with symbols outside A, C, G, T (N matches everything, anything else nothing: pairhmm_internal.cpp:27-41) are not
 // representable in a four-symbol table.  The staging loop notices them (one `v_perm_b32` per four bases), and a workgroup that holds
