@@ -58,6 +58,8 @@ __global__ void k(float* out, int iters, unsigned long long* clk)
         if (MODE == 32) { REP8(asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));) }
         if (MODE == 33) { REP8(asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %0, %0, %4, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));) }
         if (MODE == 34) { REP8(asm volatile("v_cndmask_b32 %0, %2, %3, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %0, %3, %2, vcc\n v_cndmask_b32 %1, %3, %2, vcc\n v_cndmask_b32 %0, %2, %3, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %0, %3, %2, vcc\n v_cndmask_b32 %1, %3, %2, vcc" : "+v"(a0), "+v"(a1) : "v"(b), "v"(c) : );) }
+        if (MODE == 35) { REP8(asm volatile("v_add_u32_sdwa %0, %0, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_add_u32_sdwa %1, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n v_add_u32_sdwa %3, %3, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n v_add_u32_sdwa %4, %4, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n v_add_u32_sdwa %0, %0, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_add_u32_sdwa %1, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n v_add_u32_sdwa %3, %3, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n v_add_u32_sdwa %4, %4, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
+        if (MODE == 36) { REP8(asm volatile("v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %2\n v_add_u32 %3, %3, %2\n v_add_u32 %4, %4, %2\n v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %2\n v_add_u32 %3, %3, %2\n v_add_u32 %4, %4, %2" : "+v"(m0), "+v"(m1), "+v"(a2), "+v"(a3), "+v"(a4));) }
         if (MODE == 7) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %0, %0, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -132,6 +134,9 @@ int main()
 {
     float* out; unsigned long long* clk;
     CHECK(hipMalloc(&out, 256 * 8 * 256 * sizeof(float))); CHECK(hipMalloc(&clk, 16));
+    run<36>("v_add_u32 (VOP2)", out, clk);
+    run<35>("v_add_u32_sdwa sext WORD/BYTE", out, clk);
+    if (getenv("UBENCH_NEW_ONLY")) return 0;
     run<0>("v_fma_f32 (8 indep)", out, clk);
     run<7>("v_fma_f32 (1 dependent chain)", out, clk);
     run<1>("v_pk_fma_f32 (4 indep)", out, clk);
