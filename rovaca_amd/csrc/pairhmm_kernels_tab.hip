@@ -8,6 +8,7 @@
 
 #include "pairhmm_device.h"
 #include "pairhmm_systolic_tab.h"
+#include "pairhmm_wg_timeline.h"  // (nothing unless built with -DPHMM_WG_TIMELINE: tools/wg_timeline.py)
 #ifdef PHMM_EXPERIMENT_TAB8  // tools/build_tab_variant.sh tab8 -DPHMM_EXPERIMENT_TAB8: eight lanes per pair, measured and not adopted
 #include "pairhmm_systolic_tab8.h"
 #endif
@@ -18,7 +19,9 @@ namespace phmm
 template <int K, bool UGO>
 __global__ void __launch_bounds__(256, kTabWaves) pairhmm_systolic_tab_kernel(KernelArgs a)
 {
+    PHMM_WG_TIMELINE_BEGIN();
     systolic_tab_sweep<K, UGO>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count, a.tab_slots);
+    PHMM_WG_TIMELINE_END(a);
 }
 
 template <int K, bool UGO>

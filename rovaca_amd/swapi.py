@@ -87,24 +87,37 @@ class Aligner:
     def align(self, refs, seqs, pairs, params=PARAMS_GENOTYPE):
         """refs, seqs: lists of byte strings / uint8 arrays; pairs: list of (ref index, seq index).
         -> (structured array ALIGNMENT_DTYPE per pair, uint32 array of BAM elements, SwStats)"""
-        rb, ro, rl = _tables(refs)
-        sb, so, sl = _tables(seqs)
-        pr = np.ascontiguousarray([p[0] for p in pairs], np.uint32)
-        ps = np.ascontiguousarray([p[1] for p in pairs], np.uint32)
-        n = len(pairs)
-        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
-        b = SwBatch(len(refs), len(seqs), n, ptr(rb), ptr(ro), ptr(rl), ptr(sb), ptr(so), ptr(sl), ptr(pr), ptr(ps))
-        out = np.zeros(n, ALIGNMENT_DTYPE)
-        cap = int(sum(int(rl[a]) + int(sl[c]) + 2 for a, c in pairs if a < len(rl) and c < len(sl))) if n else 0
-        cig = np.zeros(max(cap, 1), np.uint32)
+        return self.align_packed(PackedBatch(refs, seqs, pairs), params=params)
+
+    def align_packed(self, pb, params=PARAMS_GENOTYPE, out=None, cig=None):
+        """The same on a batch flattened once (PackedBatch), optionally into the caller's result arrays: what a caller that aligns the
+        same batch repeatedly, or from several threads (a context each; ctypes releases the GIL during the call), uses."""
+        n = pb.n
+        out = np.zeros(n, ALIGNMENT_DTYPE) if out is None else out
+        cig = np.zeros(max(pb.cap, 1), np.uint32) if cig is None else cig
         used = C.c_uint64()
         st = SwStats()
         par = SwParams(*params)
-        rc = lib().swhip_align(self._h, C.byref(par), C.byref(b), out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p),
-                               cap, C.byref(used), C.byref(st))
+        rc = lib().swhip_align(self._h, C.byref(par), C.byref(pb.batch), out.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p),
+                               pb.cap, C.byref(used), C.byref(st))
         if rc != 0:
             raise RuntimeError("swhip_align failed (%d): %s" % (rc, lib().swhip_last_error().decode()))
         return out, cig[:used.value], st
+
+
+class PackedBatch:
+    """refs, seqs, pairs flattened into the arrays swhip_align takes (kept alive here), and the worst-case element count."""
+
+    def __init__(self, refs, seqs, pairs):
+        self.rb, self.ro, self.rl = _tables(refs)
+        self.sb, self.so, self.sl = _tables(seqs)
+        self.pr = np.ascontiguousarray([p[0] for p in pairs], np.uint32)
+        self.ps = np.ascontiguousarray([p[1] for p in pairs], np.uint32)
+        self.n = n = len(pairs)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
+        self.batch = SwBatch(len(refs), len(seqs), n, ptr(self.rb), ptr(self.ro), ptr(self.rl), ptr(self.sb), ptr(self.so), ptr(self.sl),
+                             ptr(self.pr), ptr(self.ps))
+        self.cap = int(sum(int(self.rl[a]) + int(self.sl[c]) + 2 for a, c in pairs if a < len(self.rl) and c < len(self.sl))) if n else 0
 
 
 def cigar_of(out_row, cigars):

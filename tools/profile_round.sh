@@ -3,7 +3,10 @@
 # Kernel trace and PMC counters are separate runs; the program follows `--` directly (no wrappers).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/prof
+# profile_round.sh sw: only the Smith-Waterman part (into the same directory, next to an earlier full run's files)
+if [ "${1:-all}" != sw ]; then
+rm -rf $OUT; mkdir -p $OUT
 for c in c2 c3 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$c -o $c -- python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-adapter --no-configs > $OUT/bench_$c.log 2>&1
   tail -1 $OUT/bench_$c.log | cut -c1-160
@@ -39,11 +42,14 @@ for grp in "SQ_INSTS_VALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ
 done; done
 unset PHMM_ENABLE_TEST_HOOKS PHMM_F64_FIRST
 find $OUT -name "*.csv" | head -30
-# Smith-Waterman aligner: kernel trace of bench.py --config sw
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sw -o sw -- python3 bench.py --config sw --no-cpu-baseline > $OUT/bench_sw.log 2>&1
+fi
+mkdir -p $OUT; rm -rf $OUT/trace_sw $OUT/pmcsw_*
+# Smith-Waterman aligner: kernel trace of bench.py --config sw (without the leg of four concurrent callers, whose
+# overlapping launches would blur the lone kernel's duration)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sw -o sw -- python3 bench.py --config sw --no-cpu-baseline --no-sustained > $OUT/bench_sw.log 2>&1
 tail -1 $OUT/bench_sw.log | cut -c1-200
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-24)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcsw_$tag -o pmc -- python3 bench.py --config sw --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmcsw_$tag.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmcsw_$tag -o pmc -- python3 bench.py --config sw --steps 2 --warmup 1 --no-cpu-baseline --no-sustained > $OUT/pmcsw_$tag.log 2>&1
 done
 echo "pmc sw done"

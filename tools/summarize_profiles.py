@@ -153,7 +153,7 @@ if os.path.exists(f):
     m = re.search(r'"kernel_ms": ([0-9.]+)', open(os.path.join(src, "bench_sw.log")).read())
     valu, waves = mean.get("SQ_INSTS_VALU", 0.0), mean.get("SQ_WAVES", 1.0)
     txt = [
-        "rocprofv3 on `python3 bench.py --config sw --no-cpu-baseline` (48 000 read-vs-haplotype alignments, 150-153 x 400, genotype",
+        "rocprofv3 on `python3 bench.py --config sw --no-cpu-baseline --no-sustained` (48 000 read-vs-haplotype alignments, 150-153 x 400, genotype",
         "parameters) on MI355X (tools/profile_round.sh).  kernel: %s (16 lanes per alignment, 10 columns per lane)." % hot["Name"],
         "kernel-trace (profiles/%s_kernel_stats.csv): average %.3f ms, min %.3f ms; HIP events inside swhip_align in that run: %s ms."
         % (tag.replace("final", "sw"), ms, float(hot["MinNs"]) / 1e6, m.group(1) if m else "?"),
