@@ -304,6 +304,14 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
         const bool in_lds = l.lanes == 64 && l.count <= kLdsFlagsMaxPairs && a.lds_stride + bt_bytes <= 150u * 1024u && sw_hook("SWHIP_LDS_FLAGS");
         a.bt_in_lds = in_lds ? 1u : 0u;
         a.lds_bt_bytes = in_lds ? (uint32_t)bt_bytes : 0u;
+        // the score table of the 16-lane kernels (sw_kernels.hip): packed 16-bit scores
+        // -- if the tables leave room for four workgroups per CU (a launch with seq1 much beyond 500 bases is faster
+        // with the fourth workgroup than with the table: 150 x 1000, 3.81 against 3.85 ms)
+        // (the scores always fit: parameters are within [-512, 512], above)
+        a.score_table = l.lanes == 16 && 16u * (a.lds_stride + swhip::score_table_bytes(l.k)) <= 160u * 1024u / 4u &&
+                                !sw_hook("SWHIP_NO_SCORE_TABLE")
+                            ? 1u
+                            : 0u;
         HIP_TRY(swhip::launch_sw(l.k, l.lanes, a, st));
     }
     if (stats) HIP_TRY(hipEventRecord(c->ev1, st));

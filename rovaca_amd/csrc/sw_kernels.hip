@@ -45,10 +45,24 @@ __device__ __forceinline__ int32_t group_max(int32_t v)
     return v;
 }
 
+// Score table (round 5, 16 lanes per alignment): the scores of a lane's K columns against each of the bases A, C, G, T as packed
+// 16-bit values in LDS, [base][half][lane] x 16 bytes per alignment (K <= 8: one half).  A row's step reads the 16 or 32 bytes of its
+// seq1 base once (ds_read_b128, no bank conflicts: a lane's entries are its own, 16 bytes apart) and the cell adds the score with a
+// word-selected, sign-extended operand (v_add_u32_sdwa ... sext(src1) src1_sel:WORD_n, half rate) instead of compare, select and add:
+// 19 -> 17 instructions, 9.1 -> 4.2 cycles for the score.  Equality of arbitrary bytes is not a table lookup, so a workgroup with a byte
+// other than ACGT in any of its sequences sweeps with the compare (same results; the scores always fit, the ABI limits them to +-512).
+template <int K>
+__host__ __device__ constexpr uint32_t score_table_base_stride()
+{
+    return K > 8 ? 512u : 256u;  // bytes per base: 16 lanes x 16 bytes x (one or two halves)
+}
+
+__device__ __forceinline__ bool is_acgt(uint32_t b) { return ((0x47544341u >> (((b >> 1) & 3u) * 8u)) & 0xFFu) == b; }  // "ACTG"[(b >> 1) & 3]
+
 template <int K, int G>
 __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
 {
-    extern __shared__ uint8_t lds_seq1[];  // [alignments per block][lds_stride]: seq1 of each alignment
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_seq1[];  // [alignments per block][lds_stride]: seq1 of each alignment
     constexpr uint32_t W = (K + 7) / 8;  // backtrack words a lane produces per step
     // they are stored as W32 full dwords plus a tail of 1, 2 or 4 bytes for the last K % 8 cells, in two arrays
     // ([step][lane][W32] dwords, then [step][lane] tails): the kernel is bound by these writes, so 10 columns per lane cost
@@ -85,9 +99,47 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     const uint32_t lc = (uint32_t)(ncol - 1) / K, kc = (uint32_t)(ncol - 1) % K;  // where column ncol lives
     // seq1 is read one base per step per lane: park it in LDS (a byte load from LDS instead of a vector memory instruction)
     uint8_t *my1 = lds_seq1 + (threadIdx.x / G) * a.lds_stride;
+    bool other_bytes = false;  // a byte that is none of A, C, G, T
     if (valid)
-        for (int32_t x = (int32_t)lane; x < nrow; x += G) my1[x] = s1[x];
-    __syncthreads();
+        for (int32_t x = (int32_t)lane; x < nrow; x += G) {
+            const uint32_t b = s1[x];
+            my1[x] = (uint8_t)b;
+            other_bytes |= !is_acgt(b);
+        }
+    constexpr bool kCanTable = G == 16;
+    bool use_table = false;
+    constexpr uint32_t BS = score_table_base_stride<K>();
+    // this lane's entries for base code 0 (behind the workgroup's seq1 copies)
+    uint8_t *tab = lds_seq1 + (blockDim.x / G) * a.lds_stride + (threadIdx.x / G) * (4u * BS) + lane * 16u;
+    if constexpr (kCanTable) {
+        if (a.score_table) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) other_bytes |= base2[k] != 0x100u && !is_acgt(base2[k]);
+            use_table = !__syncthreads_or(other_bytes);
+            if (use_table) {
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const uint32_t base_c = (0x47544341u >> (c * 8u)) & 0xFFu;
+                    uint32_t packed[8];
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) packed[d] = 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint32_t sc = (base2[k] == base_c ? w_match : w_mismatch) & 0xFFFFu;
+                        packed[k / 2] |= sc << (16 * (k % 2));
+                    }
+                    *reinterpret_cast<uint4 *>(tab + c * BS) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                    if constexpr (K > 8) *reinterpret_cast<uint4 *>(tab + c * BS + 256u) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+                }
+            }
+        }
+        else {
+            __syncthreads();
+        }
+    }
+    else {
+        __syncthreads();
+    }
 
     // what this lane hands to its right neighbour: H and E of its last column in the row it has just finished; before its
     // first row that is column 0 of ... no: row 0 of that column, H = 0 and E = LOW_INIT, which is also what lane 0 keeps
@@ -109,16 +161,36 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
     asm volatile("" : "+v"(vw_match), "+v"(vw_mismatch), "+v"(vw_open), "+v"(vw_extend));
 
     uint32_t next1 = (valid && lane == 0) ? (uint32_t)my1[0] : 0u;  // seq1 base of the row this lane does next
-    // One step.  `steady` = every lane of the wave is inside its alignment and none is on its last row: no predicate, no
-    // last-row capture, the next base is always there.
-    auto step = [&](int32_t t, auto steady) {
+    // with the score table: the packed scores of this lane's columns against the base of the row it does now (cw) -- fetched during the
+    // step before, with the base read the step before that (next1 is then the base of the row AFTER the one being done)
+    constexpr int KW = K > 8 ? 8 : 4;
+    uint32_t cw[KW];
+    auto fetch_scores = [&](uint32_t base, uint32_t (&w)[KW]) __attribute__((always_inline)) {
+        const uint8_t *src = tab + ((base >> 1) & 3u) * BS;
+        const uint4 lo = *reinterpret_cast<const uint4 *>(src);
+        w[0] = lo.x, w[1] = lo.y, w[2] = lo.z, w[3] = lo.w;
+        if constexpr (KW == 8) {
+            const uint4 hi = *reinterpret_cast<const uint4 *>(src + 256u);
+            w[4] = hi.x, w[5] = hi.y, w[6] = hi.z, w[7] = hi.w;
+        }
+    };
+    // One step.  `steady` = every lane of the wave is inside its alignment and none is on its last row (with the table: nor on the
+    // row before it): no predicate, no last-row capture, the next base is always there.
+    auto step = [&](int32_t t, auto steady, auto tabbed) __attribute__((always_inline)) {
+        constexpr bool TAB = decltype(tabbed)::value;
         const int32_t i = t - (int32_t)lane;  // this lane's row
         const bool active = steady || (valid && i >= 1 && i <= nrow);
         const uint32_t diag0 = inH;           // H[i-1][jL]: what came in one step ago
         inH = (uint32_t)shr1<G>((int32_t)inH, (int32_t)outH);
         inE = (uint32_t)shr1<G>((int32_t)inE, (int32_t)outE);
         const uint32_t base1 = next1;
-        {
+        uint32_t nw[KW];
+        if constexpr (TAB) {
+            fetch_scores(next1, nw);   // row i + 1's scores
+            const int32_t ni = i + 2;  // and the base of the row after it
+            next1 = (steady || (valid && ni >= 1 && ni <= nrow)) ? (uint32_t)my1[ni - 1] : 0u;
+        }
+        else {
             const int32_t ni = i + 1;  // prefetch the base of the next row while this one is computed
             next1 = (steady || (valid && ni >= 1 && ni <= nrow)) ? (uint32_t)my1[ni - 1] : 0u;
         }
@@ -140,35 +212,99 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 // s_nop where there is none (inline assembly is not visible to the hazard recogniser).
                 uint32_t e11, f11 = F[k], h11, acc = words[k / 8];  // f11: F[i-1][j] in, F[i][j] out
                 uint32_t t_exth, t_openh, t_sc, t_m11, t_extv, t_openv, t_h1, t_d;
+                if constexpr (TAB) {
+                    // (17 instructions: the score comes out of the row's table words, the low or the high half of cw[k / 2])
+                    (void)t_sc;
+                    if (k % 2 == 0) {
+                    asm volatile(
+                            "v_add_u32 %[exth], %[e], %[wext]\n\t"
+                            "v_add_u32 %[openh], %[hl], %[wopen]\n\t"
+                            "v_add_u32_sdwa %[m11], %[hd], sext(%[scw]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                            "v_sub_co_u32 %[d], vcc, %[exth], %[openh]\n\t"   // E: the gap opens here (extension wins ties)
+                            "v_add_u32 %[extv], %[f11], %[wext]\n\t"
+                            "v_add_u32 %[openv], %[hp], %[wopen]\n\t"
+                            "v_cndmask_b32 %[e11], %[exth], %[openh], vcc\n\t"
+                            "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                            "v_sub_co_u32 %[d], vcc, %[extv], %[openv]\n\t"   // F: the gap opens here
+                            "s_nop 1\n\t"
+                            "v_cndmask_b32 %[f11], %[extv], %[openv], vcc\n\t"
+                            "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                            "v_sub_co_u32 %[d], vcc, %[m11], %[e11]\n\t"       // E beats the diagonal: insertion
+                            "s_nop 1\n\t"
+                            "v_cndmask_b32 %[h1], %[m11], %[e11], vcc\n\t"
+                            "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                            "v_sub_co_u32 %[d], vcc, %[h1], %[f11]\n\t"        // F beats both: deletion
+                            "s_nop 1\n\t"
+                            "v_cndmask_b32 %[h11], %[h1], %[f11], vcc\n\t"
+                            "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
+                            : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "+v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth),
+                              [openh] "=&v"(t_openh), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv),
+                              [h1] "=&v"(t_h1), [d] "=&v"(t_d)
+                            : [scw] "v"(cw[k / 2]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [hp] "v"(Hp[k]), [wext] "v"(vw_extend),
+                              [wopen] "v"(vw_open)
+                            : "vcc");
+                    }
+                    else {
+                    asm volatile(
+                            "v_add_u32 %[exth], %[e], %[wext]\n\t"
+                            "v_add_u32 %[openh], %[hl], %[wopen]\n\t"
+                            "v_add_u32_sdwa %[m11], %[hd], sext(%[scw]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                            "v_sub_co_u32 %[d], vcc, %[exth], %[openh]\n\t"   // E: the gap opens here (extension wins ties)
+                            "v_add_u32 %[extv], %[f11], %[wext]\n\t"
+                            "v_add_u32 %[openv], %[hp], %[wopen]\n\t"
+                            "v_cndmask_b32 %[e11], %[exth], %[openh], vcc\n\t"
+                            "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                            "v_sub_co_u32 %[d], vcc, %[extv], %[openv]\n\t"   // F: the gap opens here
+                            "s_nop 1\n\t"
+                            "v_cndmask_b32 %[f11], %[extv], %[openv], vcc\n\t"
+                            "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                            "v_sub_co_u32 %[d], vcc, %[m11], %[e11]\n\t"       // E beats the diagonal: insertion
+                            "s_nop 1\n\t"
+                            "v_cndmask_b32 %[h1], %[m11], %[e11], vcc\n\t"
+                            "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                            "v_sub_co_u32 %[d], vcc, %[h1], %[f11]\n\t"        // F beats both: deletion
+                            "s_nop 1\n\t"
+                            "v_cndmask_b32 %[h11], %[h1], %[f11], vcc\n\t"
+                            "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
+                            : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "+v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth),
+                              [openh] "=&v"(t_openh), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv),
+                              [h1] "=&v"(t_h1), [d] "=&v"(t_d)
+                            : [scw] "v"(cw[k / 2]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [hp] "v"(Hp[k]), [wext] "v"(vw_extend),
+                              [wopen] "v"(vw_open)
+                            : "vcc");
+                    }
+                }
+                else {
                 asm volatile(
-                    "v_cmp_eq_u32 vcc, %[b1], %[b2]\n\t"
-                    "v_add_u32 %[exth], %[e], %[wext]\n\t"
-                    "v_add_u32 %[openh], %[hl], %[wopen]\n\t"
-                    "v_cndmask_b32 %[sc], %[wmm], %[wm], vcc\n\t"
-                    "v_sub_co_u32 %[d], vcc, %[exth], %[openh]\n\t"   // E: the gap opens here (extension wins ties)
-                    "v_add_u32 %[m11], %[hd], %[sc]\n\t"
-                    "v_add_u32 %[extv], %[f11], %[wext]\n\t"
-                    "v_cndmask_b32 %[e11], %[exth], %[openh], vcc\n\t"
-                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
-                    "v_add_u32 %[openv], %[hp], %[wopen]\n\t"
-                    "v_sub_co_u32 %[d], vcc, %[extv], %[openv]\n\t"   // F: the gap opens here
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32 %[f11], %[extv], %[openv], vcc\n\t"
-                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
-                    "v_sub_co_u32 %[d], vcc, %[m11], %[e11]\n\t"       // E beats the diagonal: insertion
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32 %[h1], %[m11], %[e11], vcc\n\t"
-                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
-                    "v_sub_co_u32 %[d], vcc, %[h1], %[f11]\n\t"        // F beats both: deletion
-                    "s_nop 1\n\t"
-                    "v_cndmask_b32 %[h11], %[h1], %[f11], vcc\n\t"
-                    "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
-                    : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "+v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth),
-                      [openh] "=&v"(t_openh), [sc] "=&v"(t_sc), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv),
-                      [h1] "=&v"(t_h1), [d] "=&v"(t_d)
-                    : [b1] "v"(base1), [b2] "v"(base2[k]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [hp] "v"(Hp[k]),
-                      [wext] "v"(vw_extend), [wopen] "v"(vw_open), [wm] "v"(vw_match), [wmm] "v"(vw_mismatch)
-                    : "vcc");
+                        "v_cmp_eq_u32 vcc, %[b1], %[b2]\n\t"
+                        "v_add_u32 %[exth], %[e], %[wext]\n\t"
+                        "v_add_u32 %[openh], %[hl], %[wopen]\n\t"
+                        "v_cndmask_b32 %[sc], %[wmm], %[wm], vcc\n\t"
+                        "v_sub_co_u32 %[d], vcc, %[exth], %[openh]\n\t"   // E: the gap opens here (extension wins ties)
+                        "v_add_u32 %[m11], %[hd], %[sc]\n\t"
+                        "v_add_u32 %[extv], %[f11], %[wext]\n\t"
+                        "v_cndmask_b32 %[e11], %[exth], %[openh], vcc\n\t"
+                        "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                        "v_add_u32 %[openv], %[hp], %[wopen]\n\t"
+                        "v_sub_co_u32 %[d], vcc, %[extv], %[openv]\n\t"   // F: the gap opens here
+                        "s_nop 1\n\t"
+                        "v_cndmask_b32 %[f11], %[extv], %[openv], vcc\n\t"
+                        "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                        "v_sub_co_u32 %[d], vcc, %[m11], %[e11]\n\t"       // E beats the diagonal: insertion
+                        "s_nop 1\n\t"
+                        "v_cndmask_b32 %[h1], %[m11], %[e11], vcc\n\t"
+                        "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc\n\t"
+                        "v_sub_co_u32 %[d], vcc, %[h1], %[f11]\n\t"        // F beats both: deletion
+                        "s_nop 1\n\t"
+                        "v_cndmask_b32 %[h11], %[h1], %[f11], vcc\n\t"
+                        "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
+                        : [acc] "+v"(acc), [e11] "=&v"(e11), [f11] "+v"(f11), [h11] "=&v"(h11), [exth] "=&v"(t_exth),
+                          [openh] "=&v"(t_openh), [sc] "=&v"(t_sc), [m11] "=&v"(t_m11), [extv] "=&v"(t_extv), [openv] "=&v"(t_openv),
+                          [h1] "=&v"(t_h1), [d] "=&v"(t_d)
+                        : [b1] "v"(base1), [b2] "v"(base2[k]), [e] "v"(e), [hl] "v"(hl), [hd] "v"(hd), [hp] "v"(Hp[k]),
+                          [wext] "v"(vw_extend), [wopen] "v"(vw_open), [wm] "v"(vw_match), [wmm] "v"(vw_mismatch)
+                        : "vcc");
+                }
                 words[k / 8] = acc;
                 hd = Hp[k];  // the diagonal of the next column
                 h_ncol = (uint32_t)k == kc ? h11 : h_ncol;
@@ -197,22 +333,44 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                 }
             }
         }
+        if constexpr (TAB) {
+#pragma unroll
+            for (int w = 0; w < KW; ++w) cw[w] = nw[w];
+        }
     };
     // fill (lanes join one by one), steady, drain (lanes and shorter alignments leave)
-    int32_t Tsteady = valid ? nrow - 1 : 0;  // last step at which every lane of this alignment is below its last row
-    if (G == 16) {
-        Tsteady = min(Tsteady, __shfl_xor(Tsteady, 16));
-        Tsteady = min(Tsteady, __shfl_xor(Tsteady, 32));
+    auto sweep = [&](auto tabbed) __attribute__((always_inline)) {  // (forced: a call would put the column state in scratch)
+        constexpr bool TAB = decltype(tabbed)::value;
+        // last step at which every lane of this alignment is below its last row (with the table: and the one before it)
+        int32_t Tsteady = valid ? nrow - 1 - (TAB ? 1 : 0) : 0;
+        if (G == 16) {
+            Tsteady = min(Tsteady, __shfl_xor(Tsteady, 16));
+            Tsteady = min(Tsteady, __shfl_xor(Tsteady, 32));
+        }
+        Tsteady = __builtin_amdgcn_readfirstlane(Tsteady);
+        if constexpr (TAB) {  // before step 1: lane 0 is about to do row 1, lane 1 has row 1 next, lane 0 row 2
+            fetch_scores(next1, cw);
+            const int32_t r1 = 2 - (int32_t)lane;
+            next1 = (valid && r1 >= 1 && r1 <= nrow) ? (uint32_t)my1[r1 - 1] : 0u;
+        }
+        int32_t t = 1;
+        for (; t < G && t <= Tmax; ++t) step(t, std::false_type{}, tabbed);
+        for (; t + 1 <= Tsteady; t += 2) {  // two steps per trip: the row above (Hp) alternates between two register sets instead of being copied
+            step(t, std::true_type{}, tabbed);
+            step(t + 1, std::true_type{}, tabbed);
+        }
+        for (; t <= Tsteady; ++t) step(t, std::true_type{}, tabbed);
+        for (; t <= Tmax; ++t) step(t, std::false_type{}, tabbed);
+    };
+    if constexpr (kCanTable) {
+        if (use_table)
+            sweep(std::true_type{});
+        else
+            sweep(std::false_type{});
     }
-    Tsteady = __builtin_amdgcn_readfirstlane(Tsteady);
-    int32_t t = 1;
-    for (; t < G && t <= Tmax; ++t) step(t, std::false_type{});
-    for (; t + 1 <= Tsteady; t += 2) {  // two steps per trip: the row above (Hp) alternates between two register sets instead of being copied
-        step(t, std::true_type{});
-        step(t + 1, std::true_type{});
+    else {
+        sweep(std::false_type{});
     }
-    for (; t <= Tsteady; ++t) step(t, std::true_type{});
-    for (; t <= Tmax; ++t) step(t, std::false_type{});
     __threadfence_block();  // this lane's own stores are visible to the loads below (same work-item or same wave)
     __syncthreads();
 
@@ -380,7 +538,8 @@ static hipError_t launch_one(const SwArgs &a, hipStream_t s)
     const uint32_t threads = a.bt_in_lds ? (uint32_t)G : (uint32_t)kBlockThreads;  // LDS-resident flags: one alignment per workgroup
     const uint32_t per_block = threads / G;
     const uint32_t blocks = (a.n_pairs + per_block - 1) / per_block;
-    const size_t shmem = (size_t)per_block * a.lds_stride + (a.bt_in_lds ? a.lds_bt_bytes : 0u);
+    const size_t shmem = (size_t)per_block * a.lds_stride + (a.bt_in_lds ? a.lds_bt_bytes : 0u) +
+                         (G == 16 && a.score_table ? (size_t)per_block * score_table_bytes(K) : 0u);
     if (shmem > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_kernel<K, G>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);

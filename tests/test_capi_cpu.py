@@ -183,3 +183,29 @@ int main(void)
         out = subprocess.run([exe], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
         assert out.stdout.split() == ["5", "1", str(ctypes.sizeof(capi.PhmmBatch))]
+
+
+def test_sw_kernels_keep_their_column_state_out_of_scratch(tmp_path):
+    """A Smith-Waterman kernel whose per-column arrays (H and F of the row above, the bases) end up in scratch still computes the
+    right results, eight times more slowly: round 5 saw it when a wrapper lambda kept the step from being inlined (the 16-column
+    kernels went from 3.6 to 30 ms on 250-base reads).  Device assembly of every instantiation: at most the few dwords of SGPR
+    spills the widest kernels have, and no spilled VGPRs."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rovaca_amd", "csrc")
+    flags = subprocess.run(["make", "-s", "-C", csrc, "print-hipflags"], check=True, capture_output=True, text=True).stdout.split()
+    asm = tmp_path / "sw.s"
+    subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", "-o", str(asm), os.path.join(csrc, "sw_kernels.hip")], check=True,
+                   capture_output=True)
+    text = asm.read_text()
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(\S*sw_kernel\S*)\n(.*?)\.vgpr_spill_count:\s+(\d+)", text, re.S):
+        seen += 1
+        private = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", m.group(2)).group(1))
+        assert private <= 64 and int(m.group(3)) == 0, (m.group(1), private, m.group(3))
+    assert seen >= 19, seen

@@ -378,3 +378,61 @@ def test_c_batch_entry_on_the_reference_made_goldens(tag):
             continue
         assert tuple(int(x) for x in result[k, :4]) == tuple(int(x) for x in res[k][:4]), k
         assert np.array_equal(cigars[cigar_at[k]:cigar_at[k] + result[k, 4]], gc[coff[k]:coff[k + 1]]), k
+
+
+def _mutated_reads(rng, n_refs, n_reads, ref_len, read_len):
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    refs = [acgt[rng.integers(0, 4, ref_len)] for _ in range(n_refs)]
+    seqs, pairs = [], []
+    for i in range(n_reads):
+        h = refs[i % n_refs]
+        a = int(rng.integers(0, ref_len - read_len + 1))
+        r = h[a:a + read_len].copy()
+        r[rng.random(read_len) < 0.03] = ord("G")
+        if i % 5 == 0:
+            k = int(rng.integers(1, read_len - 1))
+            r = np.concatenate([r[:k], acgt[rng.integers(0, 4, 2)], r[k:]])
+        seqs.append(r)
+        pairs.append((i % n_refs, i))
+    return refs, seqs, pairs
+
+
+@pytest.mark.parametrize("read_len", [40, 100, 150, 250])
+def test_score_table_and_compare_sweeps_agree_and_other_bytes_fall_back(aligner, read_len, monkeypatch):
+    # The 16-lane kernels look the scores up in a per-alignment table of the bases A, C, G, T (sw_kernels.hip); a workgroup with any
+    # other byte in its sequences -- N, lower case, anything: the reference compares bytes -- sweeps with the compare.  Clean and
+    # unclean alignments in the same launch, against the CPU restatement, and the same batch with the table switched off.
+    monkeypatch.setenv("SWHIP_FORCE_LANES", "16")
+    rng = np.random.default_rng(300 + read_len)
+    refs, seqs, pairs = _mutated_reads(rng, 12, 160, 400, read_len)
+    # (a launch takes the alignments in order of their index here -- equal seq1 lengths --, sixteen per workgroup: the first three
+    # workgroups see other bytes, the remaining seven take the table)
+    for i in range(0, 48, 7):  # a byte that is none of ACGT in some reads
+        b = [ord("N"), ord("a"), 0, 255, ord("R")][(i // 7) % 5]
+        seqs[i] = seqs[i].copy()
+        seqs[i][int(rng.integers(0, len(seqs[i])))] = b
+    with_n = refs[3].copy()
+    with_n[[5, 77, 300]] = ord("N")  # and a haplotype with Ns (N == N is a match, as any equal bytes are)
+    refs.append(with_n)
+    seqs[2] = seqs[2].copy()
+    seqs[2][10] = ord("N")
+    for i in (2, 3, 20):
+        pairs[i] = (len(refs) - 1, i)
+    for params in (swapi.PARAMS_GENOTYPE, swapi.PARAMS_ASSEMBLE):
+        out, cig, _ = _check(aligner, refs, seqs, pairs, params)
+        monkeypatch.setenv("SWHIP_NO_SCORE_TABLE", "1")
+        out2, cig2, _ = aligner.align(refs, seqs, pairs, params)
+        monkeypatch.delenv("SWHIP_NO_SCORE_TABLE")
+        for f in ("score", "max_i", "max_j", "alignment_offset", "cigar_count"):
+            assert np.array_equal(out[f], out2[f]), f
+        for p in range(len(pairs)):
+            assert np.array_equal(swapi.cigar_of(out[p], cig), swapi.cigar_of(out2[p], cig2)), p
+
+
+def test_score_table_at_the_parameter_limits(aligner, monkeypatch):
+    # (scoring parameters are limited to [-512, 512]: the table's 16-bit entries always hold them)
+    monkeypatch.setenv("SWHIP_FORCE_LANES", "16")
+    rng = np.random.default_rng(77)
+    refs, seqs, pairs = _mutated_reads(rng, 4, 48, 300, 120)
+    for params in ((512, -512, -512, -1), (-512, 512, -3, -2), (1, -1, -512, -512)):
+        _check(aligner, refs, seqs, pairs, params)

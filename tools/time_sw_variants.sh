@@ -8,7 +8,7 @@ OUT=gpurun_out/swvar; mkdir -p $OUT
 for v in "$@"; do
   if [ $v = regular ]; then unset ROVACA_AMD_SW_LIB; else export ROVACA_AMD_SW_LIB=$PWD/rovaca_amd/lib/variants/libsw_$v.so; fi
   rm -rf $OUT/$v
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$v -o t -- python3 bench.py --config sw --steps 10 --warmup 2 --no-cpu-baseline > $OUT/$v.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$v -o t -- python3 bench.py --config sw --steps 10 --warmup 2 --no-cpu-baseline --no-sustained > $OUT/$v.log 2>&1
   f=$(find $OUT/$v -name "*kernel_stats.csv" | head -1)
   echo "$v: $(python3 -c "
 import csv, sys
