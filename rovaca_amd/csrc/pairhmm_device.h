@@ -102,7 +102,6 @@ struct KernelArgs
     const uint32_t *hap_off;
     uint32_t tab_max_hap;
     uint32_t tab_slots;  // tables per workgroup (LDS)
-    uint32_t tab_max_read;  // longest read of the launch (read by the eight-lane experiment only: -DPHMM_EXPERIMENT_TAB8)
     uint32_t band_tab;      // the fp64 band kernel may take its table form (hap_bases / hap_off / tab_max_hap set)
 };
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;

@@ -9,9 +9,6 @@
 #include "pairhmm_device.h"
 #include "pairhmm_systolic_tab.h"
 #include "pairhmm_wg_timeline.h"  // (nothing unless built with -DPHMM_WG_TIMELINE: tools/wg_timeline.py)
-#ifdef PHMM_EXPERIMENT_TAB8  // tools/build_tab_variant.sh tab8 -DPHMM_EXPERIMENT_TAB8: eight lanes per pair, measured and not adopted
-#include "pairhmm_systolic_tab8.h"
-#endif
 
 namespace phmm
 {
@@ -64,52 +61,10 @@ uint32_t tab_slots_for(int rows_per_lane, uint32_t max_hap, uint32_t lds_budget)
     return slots;
 }
 
-#ifdef PHMM_EXPERIMENT_TAB8
-// EXPERIMENT: eight lanes per pair (pairhmm_systolic_tab8.h), reads of 145-160 bases only
-#ifndef PHMM_TAB8_WAVES
-#define PHMM_TAB8_WAVES 4
-#endif
-template <int K, bool UGO>
-__global__ void __launch_bounds__(256, PHMM_TAB8_WAVES) pairhmm_systolic_tab8_kernel(KernelArgs a)
-{
-    systolic_tab8_sweep<K, UGO>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count, a.tab_slots);
-}
-static hipError_t launch_systolic_tab8_f32(int rows_per_lane, bool uniform_gop, const KernelArgs &a0, hipStream_t s)
-{
-    KernelArgs a = a0;
-    if (a.xcd_run_log2) a.xcd_run_log2 -= 1;  // runs of 32 workgroups: the same 1 024 pairs
-    const uint32_t blocks = (a.n_pairs + 31u) / 32u;
-    uint32_t grid = blocks;
-    if (a.xcd_run_log2) {
-        const uint32_t round = 8u << a.xcd_run_log2;
-        grid = (blocks + round - 1) / round * round;
-    }
-    const uint32_t budget = tab_lds_budget(PHMM_TAB8_WAVES);
-    uint32_t slots = 32;
-    while (slots && tab8_lds_bytes(rows_per_lane, slots, a.tab_max_hap) > budget) --slots;
-    if (!slots) return hipErrorInvalidValue;
-    a.tab_slots = slots;
-    const size_t shmem = tab8_lds_bytes(rows_per_lane, slots, a.tab_max_hap);
-    if (rows_per_lane == 19 && uniform_gop) hipLaunchKernelGGL((pairhmm_systolic_tab8_kernel<19, true>), dim3(grid), dim3(256), shmem, s, a);
-    else if (rows_per_lane == 19) hipLaunchKernelGGL((pairhmm_systolic_tab8_kernel<19, false>), dim3(grid), dim3(256), shmem, s, a);
-    else if (rows_per_lane == 20 && uniform_gop) hipLaunchKernelGGL((pairhmm_systolic_tab8_kernel<20, true>), dim3(grid), dim3(256), shmem, s, a);
-    else if (rows_per_lane == 20) hipLaunchKernelGGL((pairhmm_systolic_tab8_kernel<20, false>), dim3(grid), dim3(256), shmem, s, a);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-}
-
-#endif
-
 hipError_t launch_systolic_tab_f32(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s)
 {
     if (a.n_pairs == 0) return hipSuccess;
     if (!a.hap_bases || !a.hap_off || a.tab_slots == 0 || a.tab_slots > 16) return hipErrorInvalidValue;
-#ifdef PHMM_EXPERIMENT_TAB8
-    {
-        const int k8 = (int)((a.tab_max_read + 7) / 8);
-        if (getenv("PHMM_TAB8") && (k8 == 19 || k8 == 20)) return launch_systolic_tab8_f32(k8, uniform_gop, a, s);
-    }
-#endif
     return uniform_gop ? launch_tab_k<true, 1>(rows_per_lane, a, s) : launch_tab_k<false, 1>(rows_per_lane, a, s);
 }
 

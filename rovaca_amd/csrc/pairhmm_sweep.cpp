@@ -302,7 +302,6 @@ int sweep_fp32(phmm_context *c, phmm_resident *rb)
                 a.hap_off = rb->hap_off.p;
                 a.tab_max_hap = bin.max_hap_len;
                 a.tab_slots = tab_slots;
-                a.tab_max_read = bin.max_read_len;
                 HIP_TRY(phmm::launch_systolic_tab_f32(k, rb->uniform_gop, a, stream));
             }
             else

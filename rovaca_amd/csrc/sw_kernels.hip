@@ -14,9 +14,11 @@
 // alignments per wave, DPP row_shr; 64: one per wave, wave_shr); lane l owns K consecutive columns of seq2 in VGPRs (H and F of
 // the row above, the bases), and at step t computes row t - l of its columns.  E runs left to right inside the lane and
 // crosses to the next lane together with H through two DPP moves per step; the lane keeps last step's incoming H as the
-// diagonal of its first column.  Backtrack flags are 4 sign bits per cell, appended with v_alignbit, 8 cells per dword.
-// The end-cell search is a parallel max followed by an in-order pass over the few cells that attain it; the traceback is
-// one lane walking the flags (latency-bound, overlapped with other waves' sweeps).
+// diagonal of its first column.  Backtrack flags are 4 comparison bits per cell, appended with v_addc_co_u32 (the borrow of the
+// v_sub_co_u32 that made the comparison), 8 cells per dword.  With 16 lanes the score of a cell comes out of a per-alignment table
+// in LDS (below).  The end-cell search is a parallel max followed by an in-order pass over the few cells that attain it; the
+// traceback is walked by the alignment's lanes together, a fetch per G diagonal moves (bound by the sectors it touches, overlapped
+// with other workgroups' sweeps).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
