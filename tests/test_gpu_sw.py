@@ -436,3 +436,35 @@ def test_score_table_at_the_parameter_limits(aligner, monkeypatch):
     refs, seqs, pairs = _mutated_reads(rng, 4, 48, 300, 120)
     for params in ((512, -512, -512, -1), (-512, 512, -3, -2), (1, -1, -512, -512)):
         _check(aligner, refs, seqs, pairs, params)
+
+
+def test_several_contexts_on_several_threads_agree():
+    # what bench.py's `sustained` leg and the adapter's dispatchers do: a context per host thread, calls in flight together
+    import threading
+
+    rng = np.random.default_rng(11)
+    refs, seqs, pairs = _mutated_reads(rng, 40, 4000, 400, 150)
+    pb = swapi.PackedBatch(refs, seqs, pairs)
+    als = [swapi.Aligner(0) for _ in range(3)]
+    res = [None] * len(als)
+
+    def work(i):
+        for _ in range(3):
+            res[i] = als[i].align_packed(pb)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(als))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    out0, cig0, _ = res[0]
+    for out, cig, _ in res[1:]:
+        for f in ("score", "max_i", "max_j", "alignment_offset", "cigar_count"):
+            assert np.array_equal(out[f], out0[f]), f
+        for p in range(0, len(pairs), 37):  # (element offsets come from an atomic cursor: compare the elements themselves)
+            assert np.array_equal(swapi.cigar_of(out[p], cig), swapi.cigar_of(out0[p], cig0)), p
+    for p in range(0, len(pairs), 101):
+        o = oracle.sw_align(refs[pairs[p][0]], seqs[pairs[p][1]])
+        assert int(out0[p]["score"]) == o["score"] and np.array_equal(swapi.cigar_of(out0[p], cig0), o["cigar"])
+    for a in als:
+        a.close()
