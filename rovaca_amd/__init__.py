@@ -33,7 +33,7 @@ def kernel_source_id():
     return _source_id(("pairhmm_kernels.hip", "pairhmm_systolic.h", "pairhmm_systolic_sweep.inc", "pairhmm_systolic_ugo_sweep.inc",
                        "pairhmm_kernels_ragged.hip", "pairhmm_kernels_tab.hip", "pairhmm_kernels_ragged_tab.hip", "pairhmm_systolic_tab.h",
                        "pairhmm_systolic_tab_round.inc",
-                       "pairhmm_device.h"))
+                       "pairhmm_device.h", "pairhmm_tab_sched.mk"))
 
 
 def sw_kernel_source_id():

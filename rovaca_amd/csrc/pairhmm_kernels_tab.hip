@@ -1,6 +1,10 @@
 // pairhmm_kernels_tab.hip -- the one-K launches of the table sweep (pairhmm_systolic_tab.h): the single-pass systolic sweep with the
 // prior looked up in an LDS table per read instead of selected by a match bit, gfx950.  One launch per rows-per-lane class, 16 lanes per
 // pair, 256-thread workgroups (the four waves of a workgroup land on the four SIMDs of a CU; one-wave workgroups measured 8 % slower).
+//
+// Compiled three times, -DPHMM_TAB_SCHED=0 / 1 / 2, each with another instruction scheduler of the compiler (csrc/pairhmm_tab_sched.mk);
+// a build holds the kernels of the classes that tab_plan (pairhmm_systolic_tab.h) assigns to it, build 0 also everything that is not
+// a template.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -8,6 +12,12 @@
 
 #include "pairhmm_device.h"
 #include "pairhmm_systolic_tab.h"
+#ifndef PHMM_TAB_SCHED
+#define PHMM_TAB_SCHED 0
+#endif
+#if PHMM_TAB_SCHED != 0
+#undef PHMM_WG_TIMELINE  // (the time line's ring lives in build 0: tools/build_tab_variant.sh wgtl -DPHMM_WG_TIMELINE -DPHMM_TAB_ONE_BUILD)
+#endif
 #include "pairhmm_wg_timeline.h"  // (nothing unless built with -DPHMM_WG_TIMELINE: tools/wg_timeline.py)
 
 namespace phmm
@@ -17,13 +27,17 @@ template <int K, bool UGO>
 __global__ void __launch_bounds__(256, kTabWaves) pairhmm_systolic_tab_kernel(KernelArgs a)
 {
     PHMM_WG_TIMELINE_BEGIN();
-    systolic_tab_sweep<K, UGO>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count, a.tab_slots);
+    systolic_tab_sweep<K, UGO, tab_plan(K, UGO).one_loop>(a, xcd_local_workgroup(blockIdx.x, a.xcd_run_log2), 0u, a.n_pairs, a.rescue_list, a.rescue_count, a.tab_slots);
     PHMM_WG_TIMELINE_END(a);
 }
 
 template <int K, bool UGO>
 static hipError_t launch_tab_one(const KernelArgs &a, hipStream_t s)
 {
+    if constexpr (tab_plan(K, UGO).sched != PHMM_TAB_SCHED) {
+        return hipErrorInvalidValue;  // another build's class (launch_systolic_tab_f32 routes)
+    }
+    else {
     const uint32_t blocks = (a.n_pairs + 15u) / 16u;
     uint32_t grid = blocks;
     if (a.xcd_run_log2) {  // whole rounds of 8 runs (the extra workgroups find no pair)
@@ -34,6 +48,7 @@ static hipError_t launch_tab_one(const KernelArgs &a, hipStream_t s)
     const size_t shmem = std::max<size_t>(tab_lds_bytes(K, a.tab_slots, a.tab_max_hap), (size_t)16 * a.lds_words_per_group * sizeof(uint32_t));
     hipLaunchKernelGGL((pairhmm_systolic_tab_kernel<K, UGO>), dim3(grid), dim3(256), shmem, s, a);
     return hipGetLastError();
+    }
 }
 
 template <bool UGO, int K>
@@ -45,6 +60,22 @@ static hipError_t launch_tab_k(int k, const KernelArgs &a, hipStream_t s)
     else
         return hipErrorInvalidValue;
 }
+
+// this build's classes
+#if PHMM_TAB_SCHED == 0
+hipError_t launch_systolic_tab_build0(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s)
+#elif PHMM_TAB_SCHED == 1
+hipError_t launch_systolic_tab_build1(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s)
+#else
+hipError_t launch_systolic_tab_build2(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s)
+#endif
+{
+    return uniform_gop ? launch_tab_k<true, 1>(rows_per_lane, a, s) : launch_tab_k<false, 1>(rows_per_lane, a, s);
+}
+
+#if PHMM_TAB_SCHED == 0
+hipError_t launch_systolic_tab_build1(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s);
+hipError_t launch_systolic_tab_build2(int rows_per_lane, bool uniform_gop, const KernelArgs &a, hipStream_t s);
 
 uint32_t tab_lds_budget(int waves)
 {
@@ -65,7 +96,12 @@ hipError_t launch_systolic_tab_f32(int rows_per_lane, bool uniform_gop, const Ke
 {
     if (a.n_pairs == 0) return hipSuccess;
     if (!a.hap_bases || !a.hap_off || a.tab_slots == 0 || a.tab_slots > 16) return hipErrorInvalidValue;
-    return uniform_gop ? launch_tab_k<true, 1>(rows_per_lane, a, s) : launch_tab_k<false, 1>(rows_per_lane, a, s);
+    if (rows_per_lane < 1 || rows_per_lane > kTabMaxRows) return hipErrorInvalidValue;
+    switch (tab_plan(rows_per_lane, uniform_gop).sched) {
+        case kTabSchedMaxIlp: return launch_systolic_tab_build1(rows_per_lane, uniform_gop, a, s);
+        case kTabSchedIterIlp: return launch_systolic_tab_build2(rows_per_lane, uniform_gop, a, s);
+        default: return launch_systolic_tab_build0(rows_per_lane, uniform_gop, a, s);
+    }
 }
 
 // the ragged forms live in pairhmm_kernels_ragged_tab.hip, compiled once per arithmetic form
@@ -75,4 +111,5 @@ hipError_t launch_systolic_ragged_tab_f32(bool uniform_gop, const KernelArgs &a,
 {
     return uniform_gop ? launch_systolic_ragged_tab_ugo_f32(a, m, s) : launch_systolic_ragged_tab_ug_f32(a, m, s);
 }
+#endif
 }  // namespace phmm

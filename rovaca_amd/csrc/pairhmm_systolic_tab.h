@@ -73,10 +73,66 @@ __host__ __device__ inline uint32_t tab_lds_bytes(int K, uint32_t slots, uint32_
     return tab_table_region_bytes(K, slots) + 16u * tab_hap_bytes(max_hap) + 64u;
 }
 
+// ---- one class, one build ----
+// At equal instruction counts the sweep's rate moves by up to 15 % with the order hipcc schedules the instructions in and the registers
+// it picks ("Register numbers matter"), differently for every rows-per-lane class.  So the kernel of a class that is
+// launched on its own (pairhmm_kernels_tab.hip) is compiled with the instruction scheduler (-mllvm -amdgpu-sched-strategy, three builds
+// of that file: csrc/pairhmm_tab_sched.mk) and in the form of the rounds loop (below) that measured best for THAT class:
+// tools/sweep_matrix.sh, every class x form x scheduler on one box, profiles/r5_sweep_matrix.txt; a class moves only for 3 % or more.
+// The ragged kernels (every class in one kernel, one scheduler for all) keep the default scheduler and tab_one_loop_default.
+enum : int { kTabSchedDefault = 0, kTabSchedMaxIlp = 1, kTabSchedIterIlp = 2 };
+struct TabPlan
+{
+    int sched;
+    bool one_loop;
+};
+__host__ __device__ constexpr bool tab_one_loop_default(int K, bool ugo) { return ugo && (K == 5 || K == 6 || K == 9 || K == 10 || K == 11); }
+__host__ __device__ constexpr TabPlan tab_plan(int K, bool ugo)
+{
+#ifdef PHMM_TAB_ONE_BUILD  // tuning builds of the one file (tools/build_tab_variant.sh): every class in it
+    return TabPlan{kTabSchedDefault, tab_one_loop_default(K, ugo)};
+#else
+    if (ugo) {
+        switch (K) {
+            case 1: return TabPlan{kTabSchedIterIlp, true};    // 3 099 -> 3 551 GCUPS at full slots
+            case 2: return TabPlan{kTabSchedMaxIlp, true};     // 4 656 -> 4 978
+            case 3: return TabPlan{kTabSchedMaxIlp, false};    // 5 435 -> 5 614
+            case 4: return TabPlan{kTabSchedIterIlp, false};   // 5 693 -> 6 213
+            case 7: return TabPlan{kTabSchedMaxIlp, false};    // 6 766 -> 7 200
+            case 8: return TabPlan{kTabSchedMaxIlp, true};     // 7 146 -> 7 409
+            case 9: return TabPlan{kTabSchedMaxIlp, true};     // 6 813 -> 7 289
+            case 10: return TabPlan{kTabSchedIterIlp, false};  // 7 460 -> 7 698 (150-base reads: 6 930 -> 7 210)
+            case 13: return TabPlan{kTabSchedDefault, true};   // 7 236 -> 7 520
+            case 14: return TabPlan{kTabSchedDefault, true};   // 7 191 -> 7 548
+            case 15: return TabPlan{kTabSchedMaxIlp, false};   // 7 562 -> 7 921
+            case 16: return TabPlan{kTabSchedDefault, true};   // 7 492 -> 7 764
+            default: break;
+        }
+    }
+    else {
+        switch (K) {
+            case 1: return TabPlan{kTabSchedIterIlp, true};    // 3 171 -> 3 396
+            case 2: return TabPlan{kTabSchedIterIlp, true};    // 4 545 -> 4 855
+            case 3: return TabPlan{kTabSchedIterIlp, false};   // 5 056 -> 5 298
+            case 5: return TabPlan{kTabSchedIterIlp, true};    // 5 602 -> 6 007
+            case 6: return TabPlan{kTabSchedMaxIlp, true};     // 5 712 -> 6 046
+            case 7: return TabPlan{kTabSchedIterIlp, true};    // 6 205 -> 6 578
+            case 8: return TabPlan{kTabSchedIterIlp, true};    // 6 204 -> 6 775
+            case 9: return TabPlan{kTabSchedMaxIlp, false};    // 6 240 -> 6 599
+            case 13: return TabPlan{kTabSchedDefault, true};   // 6 540 -> 6 880
+            case 15: return TabPlan{kTabSchedIterIlp, true};   // 6 756 -> 6 998
+            default: break;
+        }
+    }
+    return TabPlan{kTabSchedDefault, tab_one_loop_default(K, ugo)};
+#endif
+}
+
 // UGO: one gap-open quality in the batch (pairhmm_systolic_ugo_sweep.inc); otherwise per-base gap-opens with deletion == insertion and
 // one gap-continuation quality (pairhmm_systolic_sweep.inc with UG = true: the Rovaca case with a PCR indel model).
+// ONE_LOOP: the form of the rounds loop (at the end of the function).
 // n_slots: tables the workgroup's LDS holds (1..16; the launch sized the LDS with tab_lds_bytes for it).
-template <int K, bool UGO>
+template <int K, bool UGO, bool ONE_LOOP = tab_one_loop_default(K, UGO)>
 __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t wg, uint32_t pos_first, uint32_t count, uint32_t *rescue_list,
                                                    uint32_t *rescue_count, uint32_t n_slots)
 {
@@ -217,14 +273,15 @@ __device__ __forceinline__ void systolic_tab_sweep(const KernelArgs &a, uint32_t
     // and by which registers the allocator picked ("Register numbers matter": SQ_INSTS_VALU equal, SQ_WAIT_INST_ANY 7.9e9
     // against 6.1e9).  (A second run, K = 2, 3, 5, 6, 9: 3 938 / 3 986, 4 822 / 4 770, 5 891 / 5 491, 6 319 / 6 259, 6 772 / 6 711; per-base
     // 3 773 / 3 885, 4 495 / 4 451, 5 317 / 5 222, 5 509 / 5 472, 6 358 / 6 216.)  So: the loop form for 5, 6, 9, 10 and 11 rows per lane
-    // with one gap-open quality, the straight-line form everywhere else.
+    // with one gap-open quality, the straight-line form everywhere else (tab_one_loop_default; since the classes are also built with
+    // the scheduler that suits them, the form of a class launched on its own is tab_plan's).
     // -DPHMM_TAB_LOOP_FORM_ALL / _NONE: tuning (tools/build_tab_variant.sh).
 #if defined(PHMM_TAB_LOOP_FORM_ALL)
     constexpr bool kOneLoop = true;
 #elif defined(PHMM_TAB_LOOP_FORM_NONE)
     constexpr bool kOneLoop = false;
 #else
-    constexpr bool kOneLoop = UGO && (K == 5 || K == 6 || K == 9 || K == 10 || K == 11);
+    constexpr bool kOneLoop = ONE_LOOP;
 #endif
     if constexpr (!kOneLoop) {
         {

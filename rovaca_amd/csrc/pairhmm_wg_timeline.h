@@ -1,4 +1,4 @@
-// pairhmm_wg_timeline.h -- tuning builds only (tools/build_tab_variant.sh NAME -DPHMM_WG_TIMELINE, read by tools/wg_timeline.py): when,
+// pairhmm_wg_timeline.h -- tuning builds only (tools/build_tab_variant.sh NAME -DPHMM_WG_TIMELINE -DPHMM_TAB_ONE_BUILD, read by tools/wg_timeline.py): when,
 // at what shader clock and for which launch every workgroup of the table sweep ran.  A ring of 2^18 records over launches, four words
 // each: start and end on the 100 MHz s_memrealtime clock, shader clock cycles in between (s_memtime), and the launch's grid, bits of the
 // address of its pair list and the XCC_ID.  In a regular build the two macros are empty and nothing else is declared.

@@ -1,5 +1,5 @@
 """When, where and at what shader clock the workgroups of the table sweep ran (tuning aid, GPU box).
-Needs a library built with the timeline instrumentation:  tools/build_tab_variant.sh wgtl -DPHMM_WG_TIMELINE
+Needs a library built with the timeline instrumentation:  tools/build_tab_variant.sh wgtl -DPHMM_WG_TIMELINE -DPHMM_TAB_ONE_BUILD
 usage: ROVACA_AMD_HIP_LIB=$PWD/rovaca_amd/lib/variants/lib_wgtl.so python tools/wg_timeline.py resident c2 [scale]
                                                                     python tools/wg_timeline.py oneshot c2
 resident: the last of a row of resident sweeps -- span, workgroups in flight over time, duration and clock by start order.
