@@ -304,11 +304,14 @@ static int swhip_align_impl(swhip_context *c, const swhip_params *params, const 
         const bool in_lds = l.lanes == 64 && l.count <= kLdsFlagsMaxPairs && a.lds_stride + bt_bytes <= 150u * 1024u && sw_hook("SWHIP_LDS_FLAGS");
         a.bt_in_lds = in_lds ? 1u : 0u;
         a.lds_bt_bytes = in_lds ? (uint32_t)bt_bytes : 0u;
-        // the score table of the 16-lane kernels (sw_kernels.hip): packed 16-bit scores
+        // the score table (sw_kernels.hip; up to 16 columns per lane): packed 16-bit scores
         // -- if the tables leave room for four workgroups per CU (a launch with seq1 much beyond 500 bases is faster
         // with the fourth workgroup than with the table: 150 x 1000, 3.81 against 3.85 ms)
         // (the scores always fit: parameters are within [-512, 512], above)
-        a.score_table = l.lanes == 16 && 16u * (a.lds_stride + swhip::score_table_bytes(l.k)) <= 160u * 1024u / 4u &&
+        // (one alignment per wave: from 8 columns per lane on -- the assembler's shapes, 2-3 % -- a region's 150-base reads at 3
+        // columns per lane lose 3 % to the table's set-up)
+        a.score_table = l.k <= 16 && (l.lanes == 16 || l.k >= 8) && !in_lds &&
+                                (256u / (uint32_t)l.lanes) * (a.lds_stride + swhip::score_table_bytes(l.k, l.lanes)) <= 160u * 1024u / 4u &&
                                 !sw_hook("SWHIP_NO_SCORE_TABLE")
                             ? 1u
                             : 0u;

@@ -47,7 +47,7 @@ struct SwArgs
     uint32_t lds_stride;        // bytes of LDS per alignment: the longest seq1 of the launch, rounded up
     uint32_t bt_in_lds;         // 1: backtrack flags live in LDS (lds_bt_bytes behind seq1), one alignment per workgroup
     uint32_t lds_bt_bytes;
-    uint32_t score_table;       // 1: 16-lane launches look the scores up in a per-alignment table in LDS (both scores fit 16 bits)
+    uint32_t score_table;       // 1: the launch looks the scores up in a per-alignment table in LDS (sw_kernels.hip)
     int32_t w_match, w_mismatch, w_open, w_extend;
     uint32_t *bt;               // backtrack flags; pair p starts at bt_off[p] (see bt_words)
     const uint64_t *bt_off;
@@ -77,8 +77,11 @@ inline __host__ __device__ uint64_t scratch_slots(uint32_t len1, uint32_t len2, 
     return (uint64_t)len1 + len2 + (uint64_t)len1 + len2 + 8u;  // last column, last row, element buffer
 }
 
-// LDS of the score table of one 16-lane alignment (sw_kernels.hip): four bases x 16 lanes x 16 or 32 bytes
-inline __host__ __device__ uint32_t score_table_bytes(int cols_per_lane) { return 4u * (cols_per_lane > 8 ? 512u : 256u); }
+// LDS of the score table of one alignment (sw_kernels.hip; up to 16 columns per lane): four bases x its lanes x 16 or 32 bytes
+inline __host__ __device__ uint32_t score_table_bytes(int cols_per_lane, int lanes)
+{
+    return 4u * (uint32_t)lanes * 16u * (cols_per_lane > 8 ? 2u : 1u);
+}
 
 hipError_t launch_sw(int cols_per_lane, int lanes_per_pair, const SwArgs &a, hipStream_t s);
 // the cols_per_lane values that are instantiated: round a requirement up to one of them (0 if too large)

@@ -47,16 +47,16 @@ __device__ __forceinline__ int32_t group_max(int32_t v)
     return v;
 }
 
-// Score table (round 5, 16 lanes per alignment): the scores of a lane's K columns against each of the bases A, C, G, T as packed
+// Score table (round 5; up to 16 columns per lane): the scores of a lane's K columns against each of the bases A, C, G, T as packed
 // 16-bit values in LDS, [base][half][lane] x 16 bytes per alignment (K <= 8: one half).  A row's step reads the 16 or 32 bytes of its
 // seq1 base once (ds_read_b128, no bank conflicts: a lane's entries are its own, 16 bytes apart) and the cell adds the score with a
 // word-selected, sign-extended operand (v_add_u32_sdwa ... sext(src1) src1_sel:WORD_n, half rate) instead of compare, select and add:
 // 19 -> 17 instructions, 9.1 -> 4.2 cycles for the score.  Equality of arbitrary bytes is not a table lookup, so a workgroup with a byte
 // other than ACGT in any of its sequences sweeps with the compare (same results; the scores always fit, the ABI limits them to +-512).
-template <int K>
+template <int K, int G>
 __host__ __device__ constexpr uint32_t score_table_base_stride()
 {
-    return K > 8 ? 512u : 256u;  // bytes per base: 16 lanes x 16 bytes x (one or two halves)
+    return (uint32_t)G * 16u * (K > 8 ? 2u : 1u);  // bytes per base: G lanes x 16 bytes x (one or two halves)
 }
 
 __device__ __forceinline__ bool is_acgt(uint32_t b) { return ((0x47544341u >> (((b >> 1) & 3u) * 8u)) & 0xFFu) == b; }  // "ACTG"[(b >> 1) & 3]
@@ -108,9 +108,9 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
             my1[x] = (uint8_t)b;
             other_bytes |= !is_acgt(b);
         }
-    constexpr bool kCanTable = G == 16;
+    constexpr bool kCanTable = K <= 16;  // (a lane's scores in at most two 16-byte reads; wider lanes keep the compare)
     bool use_table = false;
-    constexpr uint32_t BS = score_table_base_stride<K>();
+    constexpr uint32_t BS = score_table_base_stride<K, G>();
     // this lane's entries for base code 0 (behind the workgroup's seq1 copies)
     uint8_t *tab = lds_seq1 + (blockDim.x / G) * a.lds_stride + (threadIdx.x / G) * (4u * BS) + lane * 16u;
     if constexpr (kCanTable) {
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
                         packed[k / 2] |= sc << (16 * (k % 2));
                     }
                     *reinterpret_cast<uint4 *>(tab + c * BS) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-                    if constexpr (K > 8) *reinterpret_cast<uint4 *>(tab + c * BS + 256u) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+                    if constexpr (K > 8) *reinterpret_cast<uint4 *>(tab + c * BS + (uint32_t)G * 16u) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
                 }
             }
         }
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(kBlockThreads) sw_kernel(SwArgs a)
         const uint4 lo = *reinterpret_cast<const uint4 *>(src);
         w[0] = lo.x, w[1] = lo.y, w[2] = lo.z, w[3] = lo.w;
         if constexpr (KW == 8) {
-            const uint4 hi = *reinterpret_cast<const uint4 *>(src + 256u);
+            const uint4 hi = *reinterpret_cast<const uint4 *>(src + (uint32_t)G * 16u);
             w[4] = hi.x, w[5] = hi.y, w[6] = hi.z, w[7] = hi.w;
         }
     };
@@ -541,7 +541,7 @@ static hipError_t launch_one(const SwArgs &a, hipStream_t s)
     const uint32_t per_block = threads / G;
     const uint32_t blocks = (a.n_pairs + per_block - 1) / per_block;
     const size_t shmem = (size_t)per_block * a.lds_stride + (a.bt_in_lds ? a.lds_bt_bytes : 0u) +
-                         (G == 16 && a.score_table ? (size_t)per_block * score_table_bytes(K) : 0u);
+                         (K <= 16 && a.score_table ? (size_t)per_block * score_table_bytes(K, G) : 0u);
     if (shmem > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_kernel<K, G>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);

@@ -397,16 +397,17 @@ def _mutated_reads(rng, n_refs, n_reads, ref_len, read_len):
     return refs, seqs, pairs
 
 
-@pytest.mark.parametrize("read_len", [40, 100, 150, 250])
-def test_score_table_and_compare_sweeps_agree_and_other_bytes_fall_back(aligner, read_len, monkeypatch):
-    # The 16-lane kernels look the scores up in a per-alignment table of the bases A, C, G, T (sw_kernels.hip); a workgroup with any
-    # other byte in its sequences -- N, lower case, anything: the reference compares bytes -- sweeps with the compare.  Clean and
-    # unclean alignments in the same launch, against the CPU restatement, and the same batch with the table switched off.
-    monkeypatch.setenv("SWHIP_FORCE_LANES", "16")
+@pytest.mark.parametrize("lanes,read_len", [(16, 40), (16, 100), (16, 150), (16, 250), (64, 500), (64, 900)])
+def test_score_table_and_compare_sweeps_agree_and_other_bytes_fall_back(aligner, lanes, read_len, monkeypatch):
+    # The kernels with up to 16 columns per lane look the scores up in a per-alignment table of the bases A, C, G, T (sw_kernels.hip;
+    # with one alignment per wave from 8 columns per lane on); a workgroup with any other byte in its sequences -- N, lower case,
+    # anything: the reference compares bytes -- sweeps with the compare.  Clean and unclean alignments in the same launch, against
+    # the CPU restatement, and the same batch with the table switched off.
+    monkeypatch.setenv("SWHIP_FORCE_LANES", str(lanes))
     rng = np.random.default_rng(300 + read_len)
-    refs, seqs, pairs = _mutated_reads(rng, 12, 160, 400, read_len)
-    # (a launch takes the alignments in order of their index here -- equal seq1 lengths --, sixteen per workgroup: the first three
-    # workgroups see other bytes, the remaining seven take the table)
+    refs, seqs, pairs = _mutated_reads(rng, 12, 160, max(400, read_len + 250), read_len)
+    # (a launch takes the alignments in order of their index here -- equal seq1 lengths --, sixteen or four per workgroup: the first
+    # workgroups see other bytes, the rest take the table)
     for i in range(0, 48, 7):  # a byte that is none of ACGT in some reads
         b = [ord("N"), ord("a"), 0, 255, ord("R")][(i // 7) % 5]
         seqs[i] = seqs[i].copy()
